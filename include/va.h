@@ -1,0 +1,151 @@
+/*
+ * va.h -- C ABI of the MI355X-native two-stream inference hot path
+ *         (libva_hip.so, built from video_analytics_amd/csrc/ with hipcc for gfx950).
+ *
+ * The reference (arindamrc/video_analytics, Sheet03) has no FFI of its own: its hot path
+ * is reached through three Python call surfaces.  Each entry point
+ * below names the reference interface it stands behind:
+ *
+ *   va_vgg16_*        self.features(ip) + the classifierList traversal inside validate():
+ *                     Sheet03/spatialModel.py:110-113,127-129,136-152,212-218 and the
+ *                     temporal twin Sheet03/temporalModel.py:122-126,140-142,165-181,241-247.
+ *   va_copy_first_layer   TemporalNetwork.__copyFirstLayer__: Sheet03/temporalModel.py:149-162.
+ *   va_tvl1_flow      the upstream tool that wrote the flow_x_%04d.jpg / flow_y_%04d.jpg files
+ *                     TemporalDataset reads: Sheet03/temporalModel.py:76-81,
+ *                     Sheet03/parameters.py:27,38-39 (no reference function exists; the
+ *                     algorithm is the published TV-L1).
+ *   va_flow_to_stack  the 8-bit flow image + getTransforms' ToTensor/Normalize + the x/y
+ *                     interleave of TemporalDataset.__getitem__: Sheet03/temporalModel.py:83-90,
+ *                     Sheet03/utils.py:148-150.
+ *   va_validate_batch the loss / argmax / correct-count lines of validate():
+ *                     Sheet03/spatialModel.py:219-221.
+ *
+ * Conventions
+ *   - return 0 (VA_OK) or an error code; va_last_error() returns a thread-local message.
+ *   - every data pointer is a DEVICE pointer (hipMalloc'ed; torch tensor.data_ptr()) unless
+ *     a parameter comment says "host".  The caller owns all inputs, outputs and workspaces;
+ *     the library owns only va_ctx and the packed-weight handle.  No hidden allocation and
+ *     no host synchronisation inside va_vgg16_forward / va_tvl1_flow / va_flow_to_stack:
+ *     all work is enqueued on `stream` (a hipStream_t; NULL = the null stream).
+ *   - a handle may be used by one thread at a time; one process per GPU.
+ *   - there is NO CPU fallback in this library.
+ */
+#ifndef VA_H
+#define VA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VA_OK 0
+#define VA_ERR_INVALID 1   /* bad argument / shape: Python wrapper raises ValueError */
+#define VA_ERR_HIP 2       /* HIP runtime failure: RuntimeError */
+#define VA_ERR_WORKSPACE 3 /* workspace too small: ValueError */
+
+#define VA_DTYPE_F32 0
+#define VA_DTYPE_BF16 1
+
+typedef struct va_ctx va_ctx;
+typedef struct va_vgg16 va_vgg16;
+
+int va_version(void);
+const char* va_last_error(void);
+int va_ctx_create(int device, va_ctx** out);
+void va_ctx_destroy(va_ctx* ctx);
+
+/* ------------------------------------------------------------------ VGG-16 streams --- */
+
+/*
+ * Pack weights once.  conv_w[13]: f32 OIHW [Cout][Cin][3][3]; conv_b[13]: f32 [Cout];
+ * fc_w[4]: f32 [out][in] with FC1's input index in the reference's flatten order
+ * c*49 + h*7 + w (Sheet03/spatialModel.py:213); fc_b[4]: f32 [out].
+ * c_in is 3 (spatial) or 2L (temporal, 20).  in_mean/in_std: HOST arrays of c_in floats used
+ * only when va_vgg16_forward is given u8 input (ToTensor+Normalize, Sheet03/utils.py:148-150);
+ * may be NULL.  dtype: VA_DTYPE_F32 (fp32 in, fp32 MFMA accumulate).
+ * The call synchronises `stream` before returning (the source tensors may be freed).
+ */
+int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_dim, int dtype,
+                    const void* const* conv_w, const void* const* conv_b,
+                    const void* const* fc_w, const void* const* fc_b,
+                    const float* in_mean, const float* in_std,
+                    void* stream, va_vgg16** out);
+void va_vgg16_destroy(va_vgg16* model);
+size_t va_vgg16_workspace_bytes(const va_vgg16* model, int batch);
+
+/*
+ * x: f32 (x_is_u8 = 0) or u8 (x_is_u8 = 1) [batch][c_in][224][224] NCHW.
+ * feat: f32 [batch][512][7][7] NCHW or NULL; desc: f32 [batch][desc_dim] (post-ReLU output of
+ * classifier index 8) or NULL; logits: f32 [batch][n_classes] (no softmax) or NULL.
+ */
+int va_vgg16_forward(va_vgg16* model, const void* x, int x_is_u8, int batch,
+                     void* feat, void* desc, void* logits,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* w_rgb f32 [cout][3][3][3] -> w_out f32 [cout][n_in][3][3]: mean over the 3 input channels,
+ * accumulated in channel order then divided by 3, replicated n_in times. */
+int va_copy_first_layer(va_ctx* ctx, const void* w_rgb, int cout, int n_in, void* w_out, void* stream);
+
+/* logits f32 [batch][n_classes], labels i64 [batch] -> out f32[2] (device):
+ * out[0] = mean cross-entropy over the batch, out[1] = number of argmax(first max)==label. */
+int va_validate_batch(va_ctx* ctx, const void* logits, const void* labels, int batch, int n_classes,
+                      void* out, void* stream);
+
+/* ------------------------------------------------------------------ TV-L1 flow ------- */
+
+typedef struct va_tvl1_params {
+    float tau;        /* 0.25 */
+    float lambda;     /* 0.15 */
+    float theta;      /* 0.3  */
+    int nscales;      /* 5    */
+    int warps;        /* 5    */
+    float epsilon;    /* 0.01; <= 0: run exactly `iters` inner iterations per warp */
+    int iters;        /* 300  */
+    float scale_step; /* 0.8  */
+    int block_iters;  /* inner iterations fused per launch (register-resident temporal
+                         blocking); 0 = library default.  Results do not depend on it.
+                         Forced to 1 when epsilon > 0. */
+} va_tvl1_params;
+
+void va_tvl1_default_params(va_tvl1_params* p);
+
+/* Number of pyramid levels actually used and their sizes (ws/hs: HOST arrays of >= 16 ints). */
+int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* hs);
+
+size_t va_tvl1_workspace_bytes(int w, int h, int n_seq, int frames_per_seq, const va_tvl1_params* p);
+
+/*
+ * frames: u8 (frames_are_u8 = 1) or f32 in [0,255] [n_seq][frames_per_seq][h][w] gray.
+ * flow:   f32 [n_seq*(frames_per_seq-1)][2][h][w]; plane 0 = x flow, plane 1 = y flow of the
+ *         pair (frame k, frame k+1) of each sequence.
+ */
+int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, int n_seq, int frames_per_seq,
+                 int w, int h, const va_tvl1_params* p, void* flow,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * flow f32 [n_pairs][2][h][w] -> stack f32 [2*n_pairs][h][w]: channel 2k = x flow of pair k,
+ * 2k+1 = y flow (Sheet03/temporalModel.py:83).  Each value is quantised to the 8-bit flow
+ * image convention q = rint(clamp(255*(v+bound)/(2*bound), 0, 255)) and then normalised as
+ * (q/255 - mean)/std (Sheet03/utils.py:148-150; single-channel rule: mean 0.485, std 0.229).
+ */
+int va_flow_to_stack(va_ctx* ctx, const void* flow, int n_pairs, int w, int h,
+                     float bound, float mean, float stdv, void* stack, void* stream);
+
+/*
+ * Measurement hooks (bench.py): when enabled, va_tvl1_flow brackets every run of
+ * inner-iteration launches with HIP events on `stream`.  va_tvl1_profile_read synchronises
+ * those events and returns, summed over all va_tvl1_flow calls since the last reset:
+ * out[0] = milliseconds inside the inner-iteration kernel, out[1] = its launches,
+ * out[2] = pixel-iterations it performed (valid pixels x iterations; algorithmic bytes =
+ * 64 B x out[2]), out[3] = pixel-warps (44 B each) -- all as doubles (HOST array of 4).
+ */
+int va_tvl1_profile_enable(va_ctx* ctx, int on);
+int va_tvl1_profile_read(va_ctx* ctx, double* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VA_H */

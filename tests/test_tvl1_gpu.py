@@ -1,0 +1,106 @@
+"""GPU parity of the TV-L1 HIP path (through the C ABI) against the C oracle.
+
+The arithmetic contract (TV-L1 specification) fixes every operation, so the bar is
+BIT-EXACT flow, independent of tiling and of block_iters.  PARITY UNPINNED against the reference:
+it holds no TV-L1 code or fixtures; the oracle is pinned analytically in
+tests/test_oracle_tvl1.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(n_seq, n_frames, H, W, seed):
+    from video_analytics_amd import synth
+    _, gray, _ = synth.synth_clips(n_seq, seed=seed, H=H, W=W, n_gray=n_frames)
+    return gray
+
+
+def _run_both(oracle_tvl1, gray, **kw):
+    from video_analytics_amd import flow as vflow
+    okw = {("lambda_" if k == "lambda" else k): v for k, v in kw.items() if k != "block_iters"}
+    ref = oracle_tvl1.tvl1_flow(gray.numpy(), oracle_tvl1.default_params(**okw), nthreads=8)
+    out = vflow.tvl1_flow(gray.cuda(), **kw)
+    torch.cuda.synchronize()
+    return ref, out.cpu().numpy()
+
+
+@pytest.mark.parametrize("block_iters", [1, 3, 6])
+def test_small_fixed_bit_exact(oracle_tvl1, block_iters):
+    gray = _frames(2, 3, 48, 64, seed=11)
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=20, warps=3, block_iters=block_iters)
+    assert out.shape == ref.shape == (4, 2, 48, 64)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
+@pytest.mark.parametrize("H,W", [(224, 224), (100, 300), (179, 143), (57, 131)])
+def test_shapes_fixed_bit_exact(oracle_tvl1, H, W):
+    # 224x224: the benchmark size (all three tile configs through the pyramid);
+    # 100x300: tiled in x with a halo; odd sizes: ragged rows/columns.
+    gray = _frames(1, 3, H, W, seed=5)
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=24, warps=2)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
+def test_full_schedule_224_bit_exact(oracle_tvl1):
+    # the benchmark's exact schedule: 5 scales x 5 warps x 300 iterations, one clip's first 2 pairs
+    gray = _frames(1, 3, 224, 224, seed=0)
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
+def test_epsilon_stopping_rule_bit_exact(oracle_tvl1):
+    gray = _frames(2, 3, 96, 128, seed=7)
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.01, iters=300)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
+def test_hd_pair_bit_exact(oracle_tvl1):
+    # BASELINE config 3 geometry (1280x720), shortened schedule so the oracle finishes in seconds
+    gray = _frames(1, 2, 720, 1280, seed=3)
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=12, warps=2)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
+def test_u8_and_f32_frames_agree():
+    from video_analytics_amd import flow as vflow
+    gray = _frames(1, 3, 64, 80, seed=2)
+    a = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=10, warps=2)
+    b = vflow.tvl1_flow(gray.float().cuda(), epsilon=0.0, iters=10, warps=2)
+    assert torch.equal(a, b)
+
+
+def test_zero_motion_and_translation():
+    from video_analytics_amd import flow as vflow
+    _, gray, true_flow = __import__("video_analytics_amd.synth", fromlist=["x"]).synth_clips(1, seed=9, H=128, W=160, n_gray=2)
+    same = torch.stack([gray[0, 0], gray[0, 0]])[None]
+    z = vflow.tvl1_flow(same.cuda(), epsilon=0.0, iters=50)
+    assert float(z.abs().max()) == 0.0
+    fl = vflow.tvl1_flow(gray.cuda(), epsilon=0.0)[0].cpu()
+    c = slice(24, -24)
+    err = (fl[:, c, c] - true_flow[0][:, c, c]).abs().mean()
+    assert float(err) < 0.15, float(err)
+
+
+def test_flow_to_stack_bit_exact(oracle_tvl1):
+    from video_analytics_amd import flow as vflow
+    g = torch.Generator().manual_seed(0)
+    fl = (torch.rand(10, 2, 32, 48, generator=g) - 0.5) * 60.0
+    ref = oracle_tvl1.flow_to_stack(fl.numpy())
+    out = vflow.flow_to_stack(fl.cuda()).cpu().numpy()
+    assert out.shape == (20, 32, 48)
+    assert np.array_equal(out, ref)
+
+
+def test_bad_arguments_raise_value_error():
+    from video_analytics_amd import flow as vflow
+    with pytest.raises(ValueError):
+        vflow.tvl1_flow(torch.zeros(1, 2, 8, 8, dtype=torch.uint8, device="cuda"))  # too small
+    with pytest.raises(ValueError):
+        vflow.tvl1_flow(torch.zeros(1, 1, 64, 64, dtype=torch.uint8, device="cuda"))  # one frame
+    with pytest.raises(ValueError):
+        vflow.tvl1_flow(torch.zeros(1, 2, 64, 64, dtype=torch.uint8, device="cuda"), scale_step=1.5)
+    with pytest.raises(ValueError):
+        vflow.tvl1_flow(torch.zeros(1, 2, 64, 64, dtype=torch.uint8))  # host tensor

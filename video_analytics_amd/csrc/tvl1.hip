@@ -1,0 +1,812 @@
+// TV-L1 dense optical flow for gfx950 (MI355X): hand-written HIP, no CPU fallback.
+//
+// Replaces the unknown upstream tool that wrote the flow_x_/flow_y_ images the reference reads
+// (Sheet03/temporalModel.py:76-81, Sheet03/parameters.py:27,38-39).  The algorithm is the
+// published TV-L1 (Zach/Pock/Bischof 2007; Sanchez/Meinhardt-Llopis/Facciolo, IPOL 2013) with
+// every open choice fixed in DESIGN.md "TV-L1 specification" (steps S0..S9).  This file must be
+// compiled with -ffp-contract=off: the arithmetic contract is IEEE binary32 in the written
+// operation order with explicit fmaf only, so that results are independent of the tiling and of
+// block_iters, and comparable bit for bit with an independent implementation.
+//
+// Data layout in HBM (all fp32, row pitch = width rounded up to 4 floats so that a lane's
+// 4-pixel run is one aligned 16-byte access):
+//   pyramid  [level][frame][3 = I, Ix, Iy][h][pitch]      built once per FRAME, shared by the
+//                                                          two pairs that frame belongs to
+//   state    2 x [pair][6 = u1,u2,p11,p12,p21,p22][h][pitch]   ping-pong (halo reads vs writes)
+//   ro       [pair][4 = I1wx, I1wy, rho_c, 1/|grad|^2][h][pitch]  per-warp constants
+//
+// Dominant kernel: k_iter_tile.  One workgroup owns a (64*R) x (NW*C) pixel tile; every thread
+// keeps an R x C patch of all 10 fields in REGISTERS for `K` consecutive inner iterations
+// (temporal blocking with a K-pixel overlapped halo).  Horizontal neighbours come from the
+// adjacent lane by DPP wave shifts, vertical neighbours of the patch's first/last row from the
+// adjacent wave through a 2-row LDS exchange.  HBM traffic per pixel-iteration falls from the
+// algorithmic 64 B to about 64 B / K / tile_efficiency.
+#include "va_internal.h"
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+constexpr int kMaxScales = 16;
+constexpr int kMaxRadius = 8;
+constexpr int kNF_STATE = 6;
+constexpr int kNF_RO = 4;
+
+struct Taps {
+    float g[2 * kMaxRadius + 1];
+    int R;
+};
+
+__device__ __forceinline__ int d_min(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int d_max(int a, int b) { return a > b ? a : b; }
+
+// S3
+__device__ __forceinline__ float bilinear(const float* __restrict__ img, int w, int h, int pitch, float x, float y)
+{
+    x = fminf(fmaxf(x, 0.0f), (float)(w - 1));
+    y = fminf(fmaxf(y, 0.0f), (float)(h - 1));
+    const int x0 = (int)x, y0 = (int)y;
+    const int x1 = d_min(x0 + 1, w - 1), y1 = d_min(y0 + 1, h - 1);
+    const float ax = x - (float)x0, ay = y - (float)y0;
+    const float a = img[y0 * pitch + x0], b = img[y0 * pitch + x1];
+    const float c = img[y1 * pitch + x0], d = img[y1 * pitch + x1];
+    const float top = fmaf(ax, b - a, a);
+    const float bot = fmaf(ax, d - c, c);
+    return fmaf(ay, bot - top, top);
+}
+
+// ---------------------------------------------------------------- pyramid kernels ------------
+
+template <typename T>
+__global__ void k_frames_to_level0(const T* __restrict__ frames, float* __restrict__ pyr0, int w, int h, int pitch,
+                                   size_t plane)
+{
+    const int f = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= w * h) return;
+    const int y = idx / w, x = idx - y * w;
+    pyr0[(size_t)f * 3 * plane + (size_t)y * pitch + x] = (float)frames[(size_t)f * w * h + idx];
+}
+
+// S1: horizontal / vertical Gaussian; src and dst are [frame][stride_f floats] images of pitch `pitch`.
+template <bool VERT>
+__global__ void k_gauss(const float* __restrict__ src, size_t src_fstride, float* __restrict__ dst, size_t dst_fstride,
+                        int w, int h, int pitch, Taps t)
+{
+    const int f = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= w * h) return;
+    const int y = idx / w, x = idx - y * w;
+    const float* s = src + (size_t)f * src_fstride;
+    const int R = t.R;
+    float acc;
+    if (VERT) {
+        acc = t.g[0] * s[d_max(y - R, 0) * pitch + x];
+        for (int k = -R + 1; k <= R; ++k) acc = fmaf(t.g[k + R], s[d_min(d_max(y + k, 0), h - 1) * pitch + x], acc);
+    } else {
+        acc = t.g[0] * s[y * pitch + d_max(x - R, 0)];
+        for (int k = -R + 1; k <= R; ++k) acc = fmaf(t.g[k + R], s[y * pitch + d_min(d_max(x + k, 0), w - 1)], acc);
+    }
+    dst[(size_t)f * dst_fstride + (size_t)y * pitch + x] = acc;
+}
+
+// S1: bilinear resample of the smoothed level s-1 into level s.
+__global__ void k_resample(const float* __restrict__ src, size_t src_fstride, int w, int h, int pitch,
+                           float* __restrict__ dst, size_t dst_fstride, int ow, int oh, int opitch)
+{
+    const int f = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ow * oh) return;
+    const int y = idx / ow, x = idx - y * ow;
+    const float fx = (float)w / (float)ow, fy = (float)h / (float)oh;
+    dst[(size_t)f * dst_fstride + (size_t)y * opitch + x] =
+        bilinear(src + (size_t)f * src_fstride, w, h, pitch, (float)x * fx, (float)y * fy);
+}
+
+// S2: centred gradient of every frame's level (planes 1,2 of the frame's [3][plane] block).
+__global__ void k_grad(float* __restrict__ pyr, int w, int h, int pitch, size_t plane)
+{
+    const int f = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= w * h) return;
+    const int y = idx / w, x = idx - y * w;
+    float* base = pyr + (size_t)f * 3 * plane;
+    const float* I = base;
+    base[plane + (size_t)y * pitch + x] = 0.5f * (I[y * pitch + d_min(x + 1, w - 1)] - I[y * pitch + d_max(x - 1, 0)]);
+    base[2 * plane + (size_t)y * pitch + x] = 0.5f * (I[d_min(y + 1, h - 1) * pitch + x] - I[d_max(y - 1, 0) * pitch + x]);
+}
+
+// ---------------------------------------------------------------- per-warp kernel ------------
+
+// S5.  One thread per pixel of one pair.  The 12 bilinear taps are data-dependent gathers served
+// by L1/L2 (25 launches per pair against 7500 inner iterations: lower-order).
+__global__ void k_warp(const float* __restrict__ pyr, size_t plane, int w, int h, int pitch, int fps,
+                       const float* __restrict__ stA, const float* __restrict__ stB, const int* __restrict__ sel, int cur,
+                       int* __restrict__ base, float* __restrict__ ro)
+{
+    const int pair = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int which = sel ? sel[pair] : cur;
+    if (base && idx == 0) base[pair] = which;
+    if (idx >= w * h) return;
+    const int y = idx / w, x = idx - y * w;
+    const int seq = pair / (fps - 1), k = pair - seq * (fps - 1);
+    const int f0 = seq * fps + k;
+    const float* I0 = pyr + (size_t)f0 * 3 * plane;
+    const float* I1 = pyr + (size_t)(f0 + 1) * 3 * plane;
+    const float* st = (which ? stB : stA) + (size_t)pair * kNF_STATE * plane;
+    const size_t o = (size_t)y * pitch + x;
+    const float u1 = st[o], u2 = st[plane + o];
+    const float fxp = (float)x + u1, fyp = (float)y + u2;
+    const float Iw = bilinear(I1, w, h, pitch, fxp, fyp);
+    const float Iwx = bilinear(I1 + plane, w, h, pitch, fxp, fyp);
+    const float Iwy = bilinear(I1 + 2 * plane, w, h, pitch, fxp, fyp);
+    const float grad = fmaf(Iwy, Iwy, Iwx * Iwx);
+    float* r = ro + (size_t)pair * kNF_RO * plane;
+    r[o] = Iwx;
+    r[plane + o] = Iwy;
+    r[2 * plane + o] = fmaf(-Iwy, u2, fmaf(-Iwx, u1, Iw - I0[o]));
+    r[3 * plane + o] = grad < 1e-10f ? 0.0f : 1.0f / grad;
+}
+
+// S8.  Upsample the coarse flow (cw,ch) of buffer `which` into tmp [pair][2][fplane].  A separate
+// target is needed because with the stopping rule different pairs can hold their newest state in
+// different ping-pong buffers, and the coarse and fine layouts of different pairs overlap.
+__global__ void k_upsample(const float* __restrict__ stA, const float* __restrict__ stB, const int* __restrict__ sel,
+                           int cur, int cw, int ch, int cpitch, size_t cplane, float* __restrict__ tmp, int fw, int fh,
+                           int fpitch, size_t fplane, float inv_step)
+{
+    const int pair = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= fw * fh) return;
+    const int which = sel ? sel[pair] : cur;
+    const float* src = (which ? stB : stA) + (size_t)pair * kNF_STATE * cplane;
+    float* dst = tmp + (size_t)pair * 2 * fplane;
+    const int y = idx / fw, x = idx - y * fw;
+    const float rx = (float)cw / (float)fw, ry = (float)ch / (float)fh;
+    const size_t o = (size_t)y * fpitch + x;
+    dst[o] = bilinear(src, cw, ch, cpitch, (float)x * rx, (float)y * ry) * inv_step;
+    dst[fplane + o] = bilinear(src + cplane, cw, ch, cpitch, (float)x * rx, (float)y * ry) * inv_step;
+}
+
+// S4: start of a level: u from tmp, p = 0, everything in ping-pong buffer 0.
+__global__ void k_level_init(const float* __restrict__ tmp, float* __restrict__ st0, int w, int h, int pitch, size_t plane)
+{
+    const int pair = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= w * h) return;
+    const int y = idx / w, x = idx - y * w;
+    const size_t o = (size_t)y * pitch + x;
+    const float* t = tmp + (size_t)pair * 2 * plane;
+    float* dst = st0 + (size_t)pair * kNF_STATE * plane;
+    dst[o] = t[o];
+    dst[plane + o] = t[plane + o];
+    dst[2 * plane + o] = 0.0f;
+    dst[3 * plane + o] = 0.0f;
+    dst[4 * plane + o] = 0.0f;
+    dst[5 * plane + o] = 0.0f;
+}
+
+__global__ void k_flow_out(const float* __restrict__ stA, const float* __restrict__ stB, const int* __restrict__ sel,
+                           int cur, int w, int h, int pitch, size_t plane, float* __restrict__ flow)
+{
+    const int pair = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= w * h) return;
+    const int which = sel ? sel[pair] : cur;
+    const float* st = (which ? stB : stA) + (size_t)pair * kNF_STATE * plane;
+    const int y = idx / w, x = idx - y * w;
+    flow[((size_t)pair * 2) * w * h + idx] = st[(size_t)y * pitch + x];
+    flow[((size_t)pair * 2 + 1) * w * h + idx] = st[plane + (size_t)y * pitch + x];
+}
+
+// S9
+__global__ void k_flow_to_stack(const float* __restrict__ flow, float* __restrict__ stack, size_t n, float bound,
+                                float mean, float stdv)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float t = (255.0f * (flow[i] + bound)) / (2.0f * bound);
+    const float q = rintf(fminf(fmaxf(t, 0.0f), 255.0f));
+    stack[i] = (q / 255.0f - mean) / stdv;
+}
+
+// ---------------------------------------------------------------- inner iterations -----------
+
+struct IterArgs {
+    const float* ro;
+    const float* stA;
+    const float* stB;
+    float* outA;
+    float* outB;
+    const int* base;  // EPS mode: per-pair buffer index at the start of this warp's loop
+    int* sel;         // EPS mode: per-pair index of the buffer holding the newest state
+    unsigned long long* err;  // EPS mode: [pair][iters] exact integer error sums (S7)
+    unsigned long long qthr;
+    size_t plane;
+    int cur;  // fixed mode: input buffer index
+    int w, h, pitch;
+    int K;    // iterations in this launch
+    int ntx, nty, HX;
+    int it, iters;
+    float l_t, taut, theta;
+};
+
+__device__ __forceinline__ float dpp_from_left(float v)  // lane i <- lane i-1, lane 0 <- 0
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_from_right(float v)  // lane i <- lane i+1, lane 63 <- 0
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+template <int R>
+__device__ __forceinline__ void load_run(const float* __restrict__ row, int x0, int pitch, bool rowok, float (&v)[R])
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = 0.0f;
+    if (!rowok) return;
+    if constexpr (R == 4) {
+        if (x0 < pitch) {
+            const float4 t = *reinterpret_cast<const float4*>(row + x0);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        }
+    } else if constexpr (R == 2) {
+        if (x0 < pitch) {
+            const float2 t = *reinterpret_cast<const float2*>(row + x0);
+            v[0] = t.x; v[1] = t.y;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (x0 + r < pitch) v[r] = row[x0 + r];
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void store_run(float* __restrict__ row, int x0, int pitch, const float (&v)[R])
+{
+    if constexpr (R == 4) {
+        if (x0 < pitch) *reinterpret_cast<float4*>(row + x0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (R == 2) {
+        if (x0 < pitch) *reinterpret_cast<float2*>(row + x0) = make_float2(v[0], v[1]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (x0 + r < pitch) row[x0 + r] = v[r];
+    }
+}
+
+// S6 (+S7 when EPS).  Tile = (64*R) x (NW*C) pixels, thread patch = R x C, K iterations per launch.
+template <int R, int C, int NW, bool EPS>
+__global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
+{
+    constexpr int TW = 64 * R, TH = NW * C;
+    __shared__ float sP12[NW][TW], sP22[NW][TW], sU1[NW][TW], sU2[NW][TW];
+    __shared__ unsigned long long sErr;
+
+    const int pair = blockIdx.y;
+    int inbuf = a.cur;
+    if constexpr (EPS) {
+        // S7: a pair that met the stopping rule at iteration it-1 (or earlier: its later
+        // counters stay 0 < qthr) does nothing more in this warp.
+        if (a.it > 0 && a.err[(size_t)pair * a.iters + a.it - 1] < a.qthr) return;
+        inbuf = a.base[pair] ^ (a.it & 1);
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.sel[pair] = inbuf ^ 1;
+        if (threadIdx.x == 0) sErr = 0ull;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tx = blockIdx.x % a.ntx, ty = blockIdx.x / a.ntx;
+    const int w = a.w, h = a.h, pitch = a.pitch, K = a.K;
+    const int ox = tx * (TW - 2 * a.HX), oy = ty * (TH - 2 * K);
+    const int vx0 = ox + (tx > 0 ? a.HX : 0), vx1 = (tx == a.ntx - 1) ? w : ox + TW - a.HX;
+    const int vy0 = oy + (ty > 0 ? K : 0), vy1 = (ty == a.nty - 1) ? h : oy + TH - K;
+    const int x0 = ox + lane * R, y0 = oy + wave * C;
+
+    const float* __restrict__ ro = a.ro + (size_t)pair * kNF_RO * a.plane;
+    const float* __restrict__ sin = (inbuf ? a.stB : a.stA) + (size_t)pair * kNF_STATE * a.plane;
+    float* __restrict__ sout = (inbuf ? a.outA : a.outB) + (size_t)pair * kNF_STATE * a.plane;
+
+    float u1[C][R], u2[C][R], p11[C][R], p12[C][R], p21[C][R], p22[C][R];
+    float wx[C][R], wy[C][R], rc[C][R], ig[C][R];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int y = y0 + c;
+        const bool rowok = y < h;
+        const size_t ro_ = (size_t)y * pitch;
+        load_run<R>(sin + ro_, x0, pitch, rowok, u1[c]);
+        load_run<R>(sin + a.plane + ro_, x0, pitch, rowok, u2[c]);
+        load_run<R>(sin + 2 * a.plane + ro_, x0, pitch, rowok, p11[c]);
+        load_run<R>(sin + 3 * a.plane + ro_, x0, pitch, rowok, p12[c]);
+        load_run<R>(sin + 4 * a.plane + ro_, x0, pitch, rowok, p21[c]);
+        load_run<R>(sin + 5 * a.plane + ro_, x0, pitch, rowok, p22[c]);
+        load_run<R>(ro + ro_, x0, pitch, rowok, wx[c]);
+        load_run<R>(ro + a.plane + ro_, x0, pitch, rowok, wy[c]);
+        load_run<R>(ro + 2 * a.plane + ro_, x0, pitch, rowok, rc[c]);
+        load_run<R>(ro + 3 * a.plane + ro_, x0, pitch, rowok, ig[c]);
+    }
+
+    const float l_t = a.l_t, taut = a.taut, theta = a.theta;
+    unsigned long long qsum = 0ull;
+
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        sP12[wave][lane * R + r] = p12[C - 1][r];
+        sP22[wave][lane * R + r] = p22[C - 1][r];
+    }
+    __syncthreads();
+
+    for (int k = 0; k < K; ++k) {
+        // ---- phase A: u <- TH(u) + theta * div p   (needs p of the left and upper neighbours)
+        float Lp11[C], Lp21[C], Ap12[R], Ap22[R];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            Lp11[c] = dpp_from_left(p11[c][R - 1]);
+            Lp21[c] = dpp_from_left(p21[c][R - 1]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            Ap12[r] = wave > 0 ? sP12[wave > 0 ? wave - 1 : 0][lane * R + r] : 0.0f;
+            Ap22[r] = wave > 0 ? sP22[wave > 0 ? wave - 1 : 0][lane * R + r] : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int y = y0 + c;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int x = x0 + r;
+                const float l11 = r > 0 ? p11[c][r > 0 ? r - 1 : 0] : Lp11[c];
+                const float l21 = r > 0 ? p21[c][r > 0 ? r - 1 : 0] : Lp21[c];
+                const float a12 = c > 0 ? p12[c > 0 ? c - 1 : 0][r] : Ap12[r];
+                const float a22 = c > 0 ? p22[c > 0 ? c - 1 : 0][r] : Ap22[r];
+                const float d1x = x == 0 ? p11[c][r] : (x == w - 1 ? -l11 : p11[c][r] - l11);
+                const float d1y = y == 0 ? p12[c][r] : (y == h - 1 ? -a12 : p12[c][r] - a12);
+                const float d2x = x == 0 ? p21[c][r] : (x == w - 1 ? -l21 : p21[c][r] - l21);
+                const float d2y = y == 0 ? p22[c][r] : (y == h - 1 ? -a22 : p22[c][r] - a22);
+                const float div1 = d1x + d1y, div2 = d2x + d2y;
+                const float rho = fmaf(wy[c][r], u2[c][r], fmaf(wx[c][r], u1[c][r], rc[c][r]));
+                const float fi = fminf(fmaxf(-rho * ig[c][r], -l_t), l_t);
+                const float v1 = fmaf(fi, wx[c][r], u1[c][r]);
+                const float v2 = fmaf(fi, wy[c][r], u2[c][r]);
+                const float n1 = fmaf(theta, div1, v1);
+                const float n2 = fmaf(theta, div2, v2);
+                if constexpr (EPS) {
+                    if (x >= vx0 && x < vx1 && y >= vy0 && y < vy1) {
+                        const float e1 = n1 - u1[c][r], e2 = n2 - u2[c][r];
+                        const float e = fmaf(e2, e2, e1 * e1);
+                        qsum += (unsigned long long)(fminf(e, 1024.0f) * 4294967296.0f);
+                    }
+                }
+                u1[c][r] = n1;
+                u2[c][r] = n2;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            sU1[wave][lane * R + r] = u1[0][r];
+            sU2[wave][lane * R + r] = u2[0][r];
+        }
+        __syncthreads();
+
+        // ---- phase B: p <- (p + taut * grad u) / (1 + taut * |grad u|)   (right and lower neighbours)
+        float Ru1[C], Ru2[C], Bu1[R], Bu2[R];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            Ru1[c] = dpp_from_right(u1[c][0]);
+            Ru2[c] = dpp_from_right(u2[c][0]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            Bu1[r] = wave < NW - 1 ? sU1[wave < NW - 1 ? wave + 1 : 0][lane * R + r] : 0.0f;
+            Bu2[r] = wave < NW - 1 ? sU2[wave < NW - 1 ? wave + 1 : 0][lane * R + r] : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int y = y0 + c;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int x = x0 + r;
+                const float r1 = r < R - 1 ? u1[c][r < R - 1 ? r + 1 : 0] : Ru1[c];
+                const float r2 = r < R - 1 ? u2[c][r < R - 1 ? r + 1 : 0] : Ru2[c];
+                const float b1 = c < C - 1 ? u1[c < C - 1 ? c + 1 : 0][r] : Bu1[r];
+                const float b2 = c < C - 1 ? u2[c < C - 1 ? c + 1 : 0][r] : Bu2[r];
+                const float u1x = x < w - 1 ? r1 - u1[c][r] : 0.0f;
+                const float u1y = y < h - 1 ? b1 - u1[c][r] : 0.0f;
+                const float u2x = x < w - 1 ? r2 - u2[c][r] : 0.0f;
+                const float u2y = y < h - 1 ? b2 - u2[c][r] : 0.0f;
+                const float g1 = sqrtf(fmaf(u1y, u1y, u1x * u1x));
+                const float g2 = sqrtf(fmaf(u2y, u2y, u2x * u2x));
+                const float q1 = 1.0f / fmaf(taut, g1, 1.0f);
+                const float q2 = 1.0f / fmaf(taut, g2, 1.0f);
+                p11[c][r] = fmaf(taut, u1x, p11[c][r]) * q1;
+                p12[c][r] = fmaf(taut, u1y, p12[c][r]) * q1;
+                p21[c][r] = fmaf(taut, u2x, p21[c][r]) * q2;
+                p22[c][r] = fmaf(taut, u2y, p22[c][r]) * q2;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            sP12[wave][lane * R + r] = p12[C - 1][r];
+            sP22[wave][lane * R + r] = p22[C - 1][r];
+        }
+        __syncthreads();
+    }
+
+    // ---- write back the tile's valid interior (the valid regions partition the image)
+    const bool runok = x0 >= vx0 && x0 < vx1;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int y = y0 + c;
+        if (runok && y >= vy0 && y < vy1) {
+            const size_t ro_ = (size_t)y * pitch;
+            store_run<R>(sout + ro_, x0, pitch, u1[c]);
+            store_run<R>(sout + a.plane + ro_, x0, pitch, u2[c]);
+            store_run<R>(sout + 2 * a.plane + ro_, x0, pitch, p11[c]);
+            store_run<R>(sout + 3 * a.plane + ro_, x0, pitch, p12[c]);
+            store_run<R>(sout + 4 * a.plane + ro_, x0, pitch, p21[c]);
+            store_run<R>(sout + 5 * a.plane + ro_, x0, pitch, p22[c]);
+        }
+    }
+    if constexpr (EPS) {
+        if (qsum) atomicAdd(&sErr, qsum);
+        __syncthreads();
+        if (threadIdx.x == 0 && sErr) atomicAdd(&a.err[(size_t)pair * a.iters + a.it], sErr);
+    }
+}
+
+// ---------------------------------------------------------------- host side -------------------
+
+struct TileCfg {
+    int R, C, NW;
+};
+// Candidate tilings: ~16 pixels per thread, 512-thread workgroups (2 waves per SIMD).
+constexpr TileCfg kCfgs[] = {{4, 4, 8}, {3, 5, 8}, {2, 8, 8}};
+
+struct TilePick {
+    int cfg, ntx, nty, HX, K;
+};
+
+int tiles_1d(int n, int T, int halo)
+{
+    if (n <= T) return 1;
+    return va_cdiv(n - 2 * halo, T - 2 * halo);
+}
+
+// Pick the candidate with the fewest pixel slots for this level and K.
+TilePick pick_tiles(int w, int h, int K)
+{
+    TilePick best{};
+    double best_cost = 1e300;
+    for (int i = 0; i < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++i) {
+        const int R = kCfgs[i].R, TW = 64 * R, TH = kCfgs[i].NW * kCfgs[i].C;
+        int k = K;
+        if (h > TH && 2 * k >= TH) k = (TH - 1) / 2 > 0 ? (TH - 1) / 2 : 1;
+        const int align = (R == 4 || R == 2) ? 4 : R;  // tile origins stay vector-aligned
+        int HX = 0;
+        if (w > TW) {
+            HX = va_cdiv(k, align) * align;
+            if (2 * HX >= TW) continue;
+        }
+        const int ntx = tiles_1d(w, TW, HX), nty = tiles_1d(h, TH, k);
+        const long slots = (long)ntx * nty * TW * TH;
+        // cost ~ slots * (compute per iteration + memory amortised over k)
+        const double cost = (double)slots * (1.0 + 8.0 / k);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = TilePick{i, ntx, nty, HX, k};
+        }
+    }
+    return best;
+}
+
+template <bool EPS>
+void launch_iter(const TilePick& tp, const IterArgs& a, int npairs, hipStream_t st)
+{
+    const dim3 grid(tp.ntx * tp.nty, npairs);
+    switch (tp.cfg) {
+        case 0: k_iter_tile<4, 4, 8, EPS><<<grid, 512, 0, st>>>(a); break;
+        case 1: k_iter_tile<3, 5, 8, EPS><<<grid, 512, 0, st>>>(a); break;
+        default: k_iter_tile<2, 8, 8, EPS><<<grid, 512, 0, st>>>(a); break;
+    }
+}
+
+struct Plan {
+    int ns, ws[kMaxScales], hs[kMaxScales], pitch[kMaxScales];
+    size_t plane[kMaxScales];
+    int NF, NP, F;
+    size_t off_pyr[kMaxScales], off_tmp, off_state[2], off_ro, off_err, off_sel, total;
+};
+
+int zoom_taps(float step, Taps* t)
+{
+    const float sigma = 0.6f * sqrtf(1.0f / (step * step) - 1.0f);
+    int R = (int)(3.0f * sigma) + 1;
+    if (R > kMaxRadius) R = kMaxRadius;
+    double g[2 * kMaxRadius + 1], sum = 0.0;
+    for (int k = -R; k <= R; ++k) {
+        g[k + R] = std::exp(-(double)(k * k) / (2.0 * (double)sigma * (double)sigma));
+        sum += g[k + R];
+    }
+    for (int k = 0; k <= 2 * R; ++k) t->g[k] = (float)(g[k] / sum);
+    t->R = R;
+    return R;
+}
+
+int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
+{
+    VA_CHECK_ARG(p != nullptr, "va_tvl1: params is NULL");
+    VA_CHECK_ARG(w >= 16 && h >= 16 && w <= 16384 && h <= 16384, "va_tvl1: frame size %dx%d out of range [16,16384]", w, h);
+    VA_CHECK_ARG(n_seq >= 1 && fps >= 2, "va_tvl1: need n_seq >= 1 and frames_per_seq >= 2 (got %d, %d)", n_seq, fps);
+    VA_CHECK_ARG((long)n_seq * (fps - 1) <= 65535, "va_tvl1: more than 65535 pairs in one call");
+    VA_CHECK_ARG(p->nscales >= 1 && p->warps >= 1 && p->iters >= 1, "va_tvl1: nscales, warps, iters must be >= 1");
+    VA_CHECK_ARG(p->scale_step > 0.0f && p->scale_step < 1.0f, "va_tvl1: scale_step must be in (0,1)");
+    VA_CHECK_ARG(p->tau > 0.0f && p->lambda > 0.0f && p->theta > 0.0f, "va_tvl1: tau, lambda, theta must be > 0");
+    VA_CHECK_ARG(p->block_iters >= 0 && p->block_iters <= 64, "va_tvl1: block_iters must be in [0,64]");
+    return VA_OK;
+}
+
+int pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* hs)
+{
+    int n = 1;
+    ws[0] = w;
+    hs[0] = h;
+    const int want = p->nscales > kMaxScales ? kMaxScales : p->nscales;
+    while (n < want) {
+        const int nw = (int)((float)ws[n - 1] * p->scale_step + 0.5f);
+        const int nh = (int)((float)hs[n - 1] * p->scale_step + 0.5f);
+        if ((nw < nh ? nw : nh) < 16) break;
+        ws[n] = nw;
+        hs[n] = nh;
+        ++n;
+    }
+    return n;
+}
+
+void make_plan(Plan& P, int w, int h, int n_seq, int fps, const va_tvl1_params* p)
+{
+    P.ns = pyramid_sizes(w, h, p, P.ws, P.hs);
+    P.F = fps;
+    P.NF = n_seq * fps;
+    P.NP = n_seq * (fps - 1);
+    size_t off = 0;
+    for (int s = 0; s < P.ns; ++s) {
+        P.pitch[s] = (P.ws[s] + 3) / 4 * 4;
+        P.plane[s] = va_align_up((size_t)P.pitch[s] * P.hs[s], 64);
+        P.off_pyr[s] = off;
+        off += va_align_up((size_t)P.NF * 3 * P.plane[s] * sizeof(float), 256);
+    }
+    P.off_tmp = off;
+    off += va_align_up((size_t)P.NF * 2 * P.plane[0] * sizeof(float), 256);
+    for (int b = 0; b < 2; ++b) {
+        P.off_state[b] = off;
+        off += va_align_up((size_t)P.NP * kNF_STATE * P.plane[0] * sizeof(float), 256);
+    }
+    P.off_ro = off;
+    off += va_align_up((size_t)P.NP * kNF_RO * P.plane[0] * sizeof(float), 256);
+    P.off_err = off;
+    if (p->epsilon > 0.0f) off += va_align_up((size_t)P.NP * p->iters * sizeof(unsigned long long), 256);
+    P.off_sel = off;
+    off += va_align_up((size_t)P.NP * 2 * sizeof(int), 256);
+    P.total = off;
+}
+
+va_prof_span prof_get(va_ctx* ctx)
+{
+    va_prof_span s{};
+    if (!ctx->prof_pool.empty()) {
+        s = ctx->prof_pool.back();
+        ctx->prof_pool.pop_back();
+    } else {
+        hipEventCreate(&s.beg);
+        hipEventCreate(&s.end);
+    }
+    return s;
+}
+
+}  // namespace
+
+extern "C" void va_tvl1_default_params(va_tvl1_params* p)
+{
+    if (!p) return;
+    p->tau = 0.25f;
+    p->lambda = 0.15f;
+    p->theta = 0.3f;
+    p->nscales = 5;
+    p->warps = 5;
+    p->epsilon = 0.01f;
+    p->iters = 300;
+    p->scale_step = 0.8f;
+    p->block_iters = 0;
+}
+
+extern "C" int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* hs)
+{
+    if (!p || !ws || !hs || w < 1 || h < 1 || !(p->scale_step > 0.0f && p->scale_step < 1.0f)) return 0;
+    return pyramid_sizes(w, h, p, ws, hs);
+}
+
+extern "C" size_t va_tvl1_workspace_bytes(int w, int h, int n_seq, int frames_per_seq, const va_tvl1_params* p)
+{
+    if (check_params(p, w, h, n_seq, frames_per_seq) != VA_OK) return 0;
+    Plan P;
+    make_plan(P, w, h, n_seq, frames_per_seq, p);
+    return P.total;
+}
+
+extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, int n_seq, int frames_per_seq, int w,
+                            int h, const va_tvl1_params* p, void* flow, void* workspace, size_t workspace_bytes,
+                            void* stream)
+{
+    VA_CHECK_ARG(ctx != nullptr, "va_tvl1_flow: ctx is NULL");
+    VA_CHECK_ARG(frames != nullptr && flow != nullptr && workspace != nullptr, "va_tvl1_flow: NULL buffer");
+    if (int rc = check_params(p, w, h, n_seq, frames_per_seq)) return rc;
+    VA_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "va_tvl1_flow: workspace must be 256-byte aligned");
+    Plan P;
+    make_plan(P, w, h, n_seq, frames_per_seq, p);
+    if (workspace_bytes < P.total) {
+        va_set_error("va_tvl1_flow: workspace too small (%zu < %zu bytes)", workspace_bytes, P.total);
+        return VA_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* pyr[kMaxScales];
+    for (int s = 0; s < P.ns; ++s) pyr[s] = (float*)(ws + P.off_pyr[s]);
+    float* tmp1 = (float*)(ws + P.off_tmp);
+    float* tmp2 = tmp1 + (size_t)P.NF * P.plane[0];
+    float* state[2] = {(float*)(ws + P.off_state[0]), (float*)(ws + P.off_state[1])};
+    float* ro = (float*)(ws + P.off_ro);
+    unsigned long long* err = (unsigned long long*)(ws + P.off_err);
+    int* sel = (int*)(ws + P.off_sel);
+    int* base = sel + P.NP;
+    const bool eps = p->epsilon > 0.0f;
+    const int TPB = 256;
+
+    // S0/S1: level 0, then the pyramid of every FRAME (shared by both pairs it belongs to).
+    {
+        const dim3 g(va_cdiv(w * h, TPB), P.NF);
+        if (frames_are_u8)
+            k_frames_to_level0<unsigned char><<<g, TPB, 0, st>>>((const unsigned char*)frames, pyr[0], w, h, P.pitch[0], P.plane[0]);
+        else
+            k_frames_to_level0<float><<<g, TPB, 0, st>>>((const float*)frames, pyr[0], w, h, P.pitch[0], P.plane[0]);
+        VA_LAUNCH_CHECK();
+    }
+    Taps taps;
+    zoom_taps(p->scale_step, &taps);
+    for (int s = 1; s < P.ns; ++s) {
+        const int pw = P.ws[s - 1], ph = P.hs[s - 1], pp = P.pitch[s - 1];
+        const dim3 g(va_cdiv(pw * ph, TPB), P.NF);
+        k_gauss<false><<<g, TPB, 0, st>>>(pyr[s - 1], 3 * P.plane[s - 1], tmp1, P.plane[0], pw, ph, pp, taps);
+        k_gauss<true><<<g, TPB, 0, st>>>(tmp1, P.plane[0], tmp2, P.plane[0], pw, ph, pp, taps);
+        const dim3 g2(va_cdiv(P.ws[s] * P.hs[s], TPB), P.NF);
+        k_resample<<<g2, TPB, 0, st>>>(tmp2, P.plane[0], pw, ph, pp, pyr[s], 3 * P.plane[s], P.ws[s], P.hs[s], P.pitch[s]);
+        VA_LAUNCH_CHECK();
+    }
+    for (int s = 0; s < P.ns; ++s) {
+        const dim3 g(va_cdiv(P.ws[s] * P.hs[s], TPB), P.NF);
+        k_grad<<<g, TPB, 0, st>>>(pyr[s], P.ws[s], P.hs[s], P.pitch[s], P.plane[s]);
+        VA_LAUNCH_CHECK();
+    }
+
+    // S4: u = 0, p = 0 at the coarsest level.
+    const int sc = P.ns - 1;
+    VA_HIP(hipMemsetAsync(state[0], 0, (size_t)P.NP * kNF_STATE * P.plane[sc] * sizeof(float), st));
+    VA_HIP(hipMemsetAsync(sel, 0, (size_t)P.NP * 2 * sizeof(int), st));
+    int cur = 0;
+    int K0 = p->block_iters > 0 ? p->block_iters : 6;
+    if (eps) K0 = 1;
+
+    for (int s = sc; s >= 0; --s) {
+        const int lw = P.ws[s], lh = P.hs[s], lp = P.pitch[s];
+        const size_t plane = P.plane[s];
+        const TilePick tp = pick_tiles(lw, lh, K0);
+        const dim3 gpx(va_cdiv(lw * lh, TPB), P.NP);
+        for (int wp = 0; wp < p->warps; ++wp) {
+            k_warp<<<gpx, TPB, 0, st>>>(pyr[s], plane, lw, lh, lp, P.F, state[0], state[1], eps ? sel : nullptr, cur,
+                                         eps ? base : nullptr, ro);
+            VA_LAUNCH_CHECK();
+            if (eps) VA_HIP(hipMemsetAsync(err, 0, (size_t)P.NP * p->iters * sizeof(unsigned long long), st));
+            va_prof_span span{};
+            if (ctx->prof_on) {
+                span = prof_get(ctx);
+                VA_HIP(hipEventRecord(span.beg, st));
+            }
+            IterArgs a{};
+            a.ro = ro;
+            a.stA = state[0];
+            a.stB = state[1];
+            a.outA = state[0];
+            a.outB = state[1];
+            a.base = base;
+            a.sel = sel;
+            a.err = err;
+            a.qthr = eps ? (unsigned long long)((double)p->epsilon * (double)p->epsilon * (double)lw * (double)lh * 4294967296.0) : 0ull;
+            a.plane = plane;
+            a.w = lw;
+            a.h = lh;
+            a.pitch = lp;
+            a.ntx = tp.ntx;
+            a.nty = tp.nty;
+            a.HX = tp.HX;
+            a.iters = p->iters;
+            a.l_t = p->lambda * p->theta;
+            a.taut = p->tau / p->theta;
+            a.theta = p->theta;
+            int launches = 0;
+            for (int it = 0; it < p->iters;) {
+                const int k = (p->iters - it) < tp.K ? (p->iters - it) : tp.K;
+                a.cur = cur;
+                a.K = k;
+                a.it = it;
+                if (eps) launch_iter<true>(tp, a, P.NP, st);
+                else launch_iter<false>(tp, a, P.NP, st);
+                cur ^= 1;
+                it += k;
+                ++launches;
+            }
+            VA_LAUNCH_CHECK();
+            if (ctx->prof_on) {
+                VA_HIP(hipEventRecord(span.end, st));
+                ctx->prof_spans.push_back(span);
+                ctx->prof_launches += launches;
+                ctx->prof_pxiters += (double)P.NP * lw * lh * p->iters;
+                ctx->prof_pxwarps += (double)P.NP * lw * lh;
+            }
+        }
+        if (s > 0) {
+            // ro is free between levels: use it as the upsampling target (2 of its 4 planes per pair)
+            const dim3 g(va_cdiv(P.ws[s - 1] * P.hs[s - 1], TPB), P.NP);
+            k_upsample<<<g, TPB, 0, st>>>(state[0], state[1], eps ? sel : nullptr, cur, lw, lh, lp, plane, ro, P.ws[s - 1],
+                                           P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1], 1.0f / p->scale_step);
+            k_level_init<<<g, TPB, 0, st>>>(ro, state[0], P.ws[s - 1], P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1]);
+            VA_LAUNCH_CHECK();
+            cur = 0;
+            if (eps) VA_HIP(hipMemsetAsync(sel, 0, (size_t)P.NP * sizeof(int), st));
+        }
+    }
+    {
+        const dim3 g(va_cdiv(w * h, TPB), P.NP);
+        k_flow_out<<<g, TPB, 0, st>>>(state[0], state[1], eps ? sel : nullptr, cur, w, h, P.pitch[0], P.plane[0], (float*)flow);
+        VA_LAUNCH_CHECK();
+    }
+    return VA_OK;
+}
+
+extern "C" int va_flow_to_stack(va_ctx* ctx, const void* flow, int n_pairs, int w, int h, float bound, float mean,
+                                float stdv, void* stack, void* stream)
+{
+    VA_CHECK_ARG(ctx != nullptr, "va_flow_to_stack: ctx is NULL");
+    VA_CHECK_ARG(flow != nullptr && stack != nullptr, "va_flow_to_stack: NULL buffer");
+    VA_CHECK_ARG(n_pairs >= 1 && w >= 1 && h >= 1, "va_flow_to_stack: bad shape");
+    VA_CHECK_ARG(bound > 0.0f && stdv > 0.0f, "va_flow_to_stack: bound and std must be > 0");
+    const size_t n = (size_t)n_pairs * 2 * w * h;
+    k_flow_to_stack<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>((const float*)flow, (float*)stack, n, bound, mean, stdv);
+    VA_LAUNCH_CHECK();
+    return VA_OK;
+}
+
+extern "C" int va_tvl1_profile_enable(va_ctx* ctx, int on)
+{
+    VA_CHECK_ARG(ctx != nullptr, "va_tvl1_profile_enable: ctx is NULL");
+    ctx->prof_on = on != 0;
+    return VA_OK;
+}
+
+extern "C" int va_tvl1_profile_read(va_ctx* ctx, double* out, int reset)
+{
+    VA_CHECK_ARG(ctx != nullptr && out != nullptr, "va_tvl1_profile_read: NULL argument");
+    for (va_prof_span& s : ctx->prof_spans) {
+        VA_HIP(hipEventSynchronize(s.end));
+        float ms = 0.0f;
+        VA_HIP(hipEventElapsedTime(&ms, s.beg, s.end));
+        ctx->prof_ms += ms;
+        ctx->prof_pool.push_back(s);
+    }
+    ctx->prof_spans.clear();
+    out[0] = ctx->prof_ms;
+    out[1] = ctx->prof_launches;
+    out[2] = ctx->prof_pxiters;
+    out[3] = ctx->prof_pxwarps;
+    if (reset) ctx->prof_ms = ctx->prof_launches = ctx->prof_pxiters = ctx->prof_pxwarps = 0.0;
+    return VA_OK;
+}
