@@ -1,8 +1,706 @@
-// placeholder while the conv/FC kernels are being written (replaced in the next commit)
+// VGG-16 'D' feature stack + the reference's 4-layer classifier for gfx950 (MI355X).
+//
+// Stands behind self.features(ip) and the classifierList traversal of validate()
+// (Sheet03/spatialModel.py:110-113,127-129,136-152,212-218; temporal twin
+// Sheet03/temporalModel.py:122-126,149-181,241-247).  Hand-written HIP, no MIOpen / hipBLASLt,
+// no CPU fallback.
+//
+// Design
+//   * activations live in HBM as NHWC fp32 (channels innermost) so that the implicit-GEMM A
+//     operand (one output pixel's 3x3xCin patch) is 9 contiguous channel runs and every global
+//     access is a 16-byte lane access;
+//   * conv3x3+bias+ReLU(+maxpool2x2) is ONE kernel: implicit GEMM  D[m][n] = sum_k A[m][k] W[n][k],
+//     m = output pixel, n = output channel, k = (ky,kx,ci), on v_mfma_f32_32x32x2_f32 (fp32 in,
+//     fp32 accumulate: exact fp32 products, one rounding per FMA -- DESIGN.md "numerics");
+//   * the 128 pixels of an M tile are a (TB images) x (TH rows) x (TW cols) brick whose two lowest
+//     index bits are (x&1, y&1): the four pixels of a 2x2 pooling window are then the four
+//     accumulator registers (reg&3) of ONE lane, so the fused max-pool is register-only;
+//   * weights are repacked once into [Cout][9*Cin_pad] (K-contiguous, same shape as the A tile);
+//     the first layer's input channels are zero-padded to 16 (spatial, 3) / 32 (temporal, 20);
+//   * FC layers: the same MFMA tile as a split-K "NT" GEMM over the batch (M = 32 rows per tile),
+//     partial slabs reduced by a second kernel that fuses bias+ReLU (deterministic, no atomics).
+//     FC1's weight is repacked so that the NHWC feature map can be used without a transpose while
+//     keeping the reference's CHW-major flatten order c*49+h*7+w (Sheet03/spatialModel.py:213).
 #include "va_internal.h"
-extern "C" int va_vgg16_create(va_ctx*, int, int, int, int, const void* const*, const void* const*, const void* const*, const void* const*, const float*, const float*, void*, va_vgg16**) { va_set_error("va_vgg16: not built yet"); return VA_ERR_INVALID; }
-extern "C" void va_vgg16_destroy(va_vgg16*) {}
-extern "C" size_t va_vgg16_workspace_bytes(const va_vgg16*, int) { return 0; }
-extern "C" int va_vgg16_forward(va_vgg16*, const void*, int, int, void*, void*, void*, void*, size_t, void*) { va_set_error("va_vgg16: not built yet"); return VA_ERR_INVALID; }
-extern "C" int va_copy_first_layer(va_ctx*, const void*, int, int, void*, void*) { va_set_error("not built yet"); return VA_ERR_INVALID; }
-extern "C" int va_validate_batch(va_ctx*, const void*, const void*, int, int, void*, void*) { va_set_error("not built yet"); return VA_ERR_INVALID; }
+#include <cstring>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBK = 16;       // K chunk per LDS tile (floats)
+constexpr int kLdsStride = 20;  // floats per LDS row: 80 B keeps ds_read_b128 conflict-free
+
+// ---------------------------------------------------------------- layout / packing kernels ----
+
+// x NCHW (f32, or u8 with ToTensor+Normalize: Sheet03/utils.py:148-150) -> NHWC with C padded to cpad.
+template <typename T>
+__global__ void k_nchw_to_nhwc_pad(const T* __restrict__ x, float* __restrict__ out, int B, int C, int HW, int cpad,
+                                   const float* __restrict__ mean, const float* __restrict__ stdv)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * HW) return;
+    const int b = (int)(idx / HW), p = (int)(idx - (size_t)b * HW);
+    float* o = out + idx * cpad;
+    for (int c = 0; c < cpad; ++c) {
+        float v = 0.0f;
+        if (c < C) {
+            const T raw = x[((size_t)b * C + c) * HW + p];
+            if constexpr (sizeof(T) == 1) v = ((float)raw / 255.0f - mean[c]) / stdv[c];
+            else v = (float)raw;
+        }
+        o[c] = v;
+    }
+}
+
+// OIHW [Cout][Cin][3][3] -> [Cout][9][cpad]
+__global__ void k_pack_conv_w(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int cpad)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)Cout * 9 * cpad;
+    if (idx >= total) return;
+    const int ci = (int)(idx % cpad);
+    const int kp = (int)((idx / cpad) % 9);
+    const int n = (int)(idx / ((size_t)cpad * 9));
+    wp[idx] = ci < Cin ? w[((size_t)n * Cin + ci) * 9 + kp] : 0.0f;
+}
+
+// FC1 [out][c*HW + p] -> [out][p*C + c]
+__global__ void k_pack_fc1(const float* __restrict__ w, float* __restrict__ wp, int O, int C, int HW)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)O * C * HW;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int p = (int)((idx / C) % HW);
+    const size_t o = idx / ((size_t)C * HW);
+    wp[idx] = w[(o * C + c) * HW + p];
+}
+
+// NHWC [B][HW][C] -> NCHW [B][C][HW]  (optional `feat` output)
+__global__ void k_nhwc_to_nchw(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * C * HW) return;
+    const int p = (int)(idx % HW);
+    const int c = (int)((idx / HW) % C);
+    const size_t b = idx / ((size_t)HW * C);
+    out[idx] = in[(b * HW + p) * C + c];
+}
+
+// Sheet03/temporalModel.py:155-161
+__global__ void k_copy_first_layer(const float* __restrict__ w, float* __restrict__ out, int cout, int n_in)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cout * n_in * 9) return;
+    const int kp = idx % 9, o = idx / (9 * n_in);
+    float avg = 0.0f;
+    avg = avg + w[(o * 3 + 0) * 9 + kp];
+    avg = avg + w[(o * 3 + 1) * 9 + kp];
+    avg = avg + w[(o * 3 + 2) * 9 + kp];
+    out[idx] = avg / 3.0f;
+}
+
+// ---------------------------------------------------------------- conv3x3 implicit GEMM --------
+
+struct ConvArgs {
+    const float* in;    // NHWC [B][H][W][Cin], Cin % 16 == 0
+    const float* wp;    // [Cout][9*Cin]
+    const float* bias;  // [Cout]
+    float* out;         // NHWC [B][H][W][Cout] or pooled [B][H/2][W/2][Cout]
+    int B, H, W, Cin, Cout;
+    int lgTW, lgTH;     // log2 of the brick's width/height (>= 1)
+    int TB;
+    int tiles_x, tiles_y, tiles_n;
+};
+
+__device__ __forceinline__ void brick_coords(int m, int lgTW, int lgTH, int& xl, int& yl, int& bl)
+{
+    const int x0 = m & 1, y0 = (m >> 1) & 1;
+    int r = m >> 2;
+    const int xh = r & ((1 << (lgTW - 1)) - 1);
+    r >>= (lgTW - 1);
+    const int yh = r & ((1 << (lgTH - 1)) - 1);
+    r >>= (lgTH - 1);
+    xl = 2 * xh + x0;
+    yl = 2 * yh + y0;
+    bl = r;
+}
+
+// BM = WM*MT*32 output pixels x BN = WN*NT*32 output channels per workgroup of WM*WN waves.
+template <int WM, int WN, int MT, int NT, bool POOL>
+__global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
+{
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHR = WM * WN * 64;
+    constexpr int A_ROWS_PER_PASS = NTHR / 4, A_PASSES = BM / A_ROWS_PER_PASS, B_PASSES = BN / A_ROWS_PER_PASS;
+    static_assert(BM % A_ROWS_PER_PASS == 0 && BN % A_ROWS_PER_PASS == 0, "tile/thread mismatch");
+    __shared__ __attribute__((aligned(16))) float sA[2][BM * kLdsStride];
+    __shared__ __attribute__((aligned(16))) float sB[2][BN * kLdsStride];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int bid = blockIdx.x;
+    const int n_tile = bid % a.tiles_n;
+    bid /= a.tiles_n;
+    const int tile_x = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int tile_y = bid % a.tiles_y;
+    const int tile_b = bid / a.tiles_y;
+    const int n0 = n_tile * BN;
+    const int H = a.H, W = a.W, Cin = a.Cin;
+    const int X0 = tile_x << a.lgTW, Y0 = tile_y << a.lgTH, B0 = tile_b * a.TB;
+
+    // loader role: float4 column q of rows (tid>>2) + 64*i
+    const int q = tid & 3, rowbase = tid >> 2;
+    int ax[A_PASSES], ay[A_PASSES];
+    long apix[A_PASSES];
+    bool aok[A_PASSES];
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        int xl, yl, bl;
+        brick_coords(rowbase + A_ROWS_PER_PASS * i, a.lgTW, a.lgTH, xl, yl, bl);
+        ax[i] = X0 + xl;
+        ay[i] = Y0 + yl;
+        const int b = B0 + bl;
+        aok[i] = b < a.B && ax[i] < W && ay[i] < H;
+        apix[i] = (((long)b * H + ay[i]) * W + ax[i]) * Cin + 4 * q;
+    }
+    const float* wrow[B_PASSES];
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) wrow[i] = a.wp + (size_t)(n0 + rowbase + A_ROWS_PER_PASS * i) * 9 * Cin + 4 * q;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    const int cchunks = Cin / kBK;
+    const int T = 9 * cchunks;
+    float4 ra[A_PASSES], rb[B_PASSES];
+
+    auto gload = [&](int t) {
+        const int kp = t / cchunks, c0 = (t - kp * cchunks) * kBK;
+        const int ky = kp / 3 - 1, kx = kp % 3 - 1;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            const int yy = ay[i] + ky, xx = ax[i] + kx;
+            const bool ok = aok[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            ra[i] = ok ? *reinterpret_cast<const float4*>(a.in + apix[i] + ((long)ky * W + kx) * Cin + c0)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) rb[i] = *reinterpret_cast<const float4*>(wrow[i] + (size_t)kp * Cin + c0);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i)
+            *reinterpret_cast<float4*>(&sA[buf][(rowbase + A_ROWS_PER_PASS * i) * kLdsStride + 4 * q]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i)
+            *reinterpret_cast<float4*>(&sB[buf][(rowbase + A_ROWS_PER_PASS * i) * kLdsStride + 4 * q]) = rb[i];
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int r31 = lane & 31, hh = lane >> 5;
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T) gload(t + 1);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float4 fa[MT], fb[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                fa[mt] = *reinterpret_cast<const float4*>(&sA[buf][((wm * MT + mt) * 32 + r31) * kLdsStride + 8 * g + 4 * hh]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                fb[nt] = *reinterpret_cast<const float4*>(&sB[buf][((wn * NT + nt) * 32 + r31) * kLdsStride + 8 * g + 4 * hh]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt].x, fb[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt].y, fb[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt].z, fb[nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt].w, fb[nt].w, acc[mt][nt], 0, 0, 0);
+                }
+        }
+        if (t + 1 < T) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: bias + ReLU (+ 2x2 max-pool over the 4 registers reg&3 of a lane)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + (wn * NT + nt) * 32 + r31;
+        const float bias = a.bias[n];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                // rows m = (wm*MT+mt)*32 + 8*g4 + 4*hh + (0..3)
+                const int mbase = (wm * MT + mt) * 32 + 8 * g4 + 4 * hh;
+                int xl, yl, bl;
+                brick_coords(mbase, a.lgTW, a.lgTH, xl, yl, bl);
+                const int x = X0 + xl, y = Y0 + yl, b = B0 + bl;  // (x,y) even: the 2x2 window's origin
+                if (b >= a.B) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[mt][nt][4 * g4 + j] + bias, 0.0f);
+                if constexpr (POOL) {
+                    if (x < W && y < H) {
+                        const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        a.out[((((size_t)b * (H >> 1)) + (y >> 1)) * (W >> 1) + (x >> 1)) * a.Cout + n] = mx;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int xx = x + (j & 1), yy = y + (j >> 1);
+                        if (xx < W && yy < H) a.out[(((size_t)b * H + yy) * W + xx) * a.Cout + n] = v[j];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- FC split-K GEMM --------------
+
+struct FcArgs {
+    const float* A;   // [M][K] row-major (lda = K)
+    const float* Wt;  // [N][K]
+    float* slab;      // [S][Mtiles*32][Npad]
+    int M, N, K, S, kchunk, Npad;
+};
+
+// One workgroup: 32 rows (batch) x 128 columns x one K slice.  4 waves, each 32x32.
+__global__ void __launch_bounds__(256) k_fc_splitk(FcArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sA[2][32 * kLdsStride];
+    __shared__ __attribute__((aligned(16))) float sB[2][128 * kLdsStride];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = a.Npad / 128;
+    const int n_tile = blockIdx.x % ntiles, s = blockIdx.x / ntiles;
+    const int m0 = blockIdx.y * 32, n0 = n_tile * 128;
+    const int k0 = s * a.kchunk;
+    const int kend = (k0 + a.kchunk < a.K) ? k0 + a.kchunk : a.K;
+    const int T = (kend - k0) / kBK;
+    const int q = tid & 3, rowbase = tid >> 2;
+
+    const bool a_loader = rowbase < 32;
+    const bool a_ok = a_loader && (m0 + rowbase) < a.M;
+    const float* arow = a.A + (size_t)(m0 + (a_ok ? rowbase : 0)) * a.K + 4 * q;
+    const float* brow[2];
+    bool b_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + rowbase + 64 * i;
+        b_ok[i] = n < a.N;
+        brow[i] = a.Wt + (size_t)(b_ok[i] ? n : 0) * a.K + 4 * q;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float4 ra, rb[2];
+    auto gload = [&](int t) {
+        const int k = k0 + t * kBK;
+        ra = a_ok ? *reinterpret_cast<const float4*>(arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(brow[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto lstore = [&](int buf) {
+        if (a_loader) *reinterpret_cast<float4*>(&sA[buf][rowbase * kLdsStride + 4 * q]) = ra;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&sB[buf][(rowbase + 64 * i) * kLdsStride + 4 * q]) = rb[i];
+    };
+    const int r31 = lane & 31, hh = lane >> 5;
+    if (T > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T) gload(t + 1);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const float4 fa = *reinterpret_cast<const float4*>(&sA[buf][r31 * kLdsStride + 8 * g + 4 * hh]);
+            const float4 fb = *reinterpret_cast<const float4*>(&sB[buf][(wave * 32 + r31) * kLdsStride + 8 * g + 4 * hh]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+        }
+        if (t + 1 < T) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // slab[s][m][n]
+    const int n = n0 + wave * 32 + r31;
+    const size_t Mp = (size_t)gridDim.y * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        a.slab[((size_t)s * Mp + m) * a.Npad + n] = acc[r];
+    }
+}
+
+// out[m][n] = act(bias[n] + sum_s slab[s][m][n]); fixed summation order s = 0..S-1.
+__global__ void k_fc_reduce(const float* __restrict__ slab, const float* __restrict__ bias, float* __restrict__ out,
+                            int M, int N, int Npad, int Mp, int S, int relu)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * N) return;
+    const int m = idx / N, n = idx - m * N;
+    float acc = bias[n];
+    for (int s = 0; s < S; ++s) acc += slab[((size_t)s * Mp + m) * Npad + n];
+    out[idx] = relu ? fmaxf(acc, 0.0f) : acc;
+}
+
+// Sheet03/spatialModel.py:219-221: mean CE over the batch, first-max argmax, correct count.
+__global__ void k_validate_batch(const float* __restrict__ logits, const long long* __restrict__ labels, int B, int C,
+                                 float* __restrict__ out)
+{
+    __shared__ float sloss[256];
+    __shared__ int scorr[256];
+    float loss = 0.0f;
+    int corr = 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float* l = logits + (size_t)b * C;
+        float mx = l[0];
+        int am = 0;
+        for (int c = 1; c < C; ++c)
+            if (l[c] > mx) { mx = l[c]; am = c; }
+        float se = 0.0f;
+        for (int c = 0; c < C; ++c) se += expf(l[c] - mx);
+        const long long y = labels[b];
+        loss += (logf(se) + mx) - l[y];
+        corr += (am == (int)y);
+    }
+    sloss[threadIdx.x] = loss;
+    scorr[threadIdx.x] = corr;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float L = 0.0f;
+        int Cc = 0;
+        for (int i = 0; i < (int)blockDim.x; ++i) { L += sloss[i]; Cc += scorr[i]; }
+        out[0] = L / (float)B;
+        out[1] = (float)Cc;
+    }
+}
+
+// ---------------------------------------------------------------- host side --------------------
+
+struct ConvLayer {
+    int cin, cin_pad, cout, hw;  // hw = input height = width
+    bool pool;
+    float* wp;
+    float* bias;
+};
+
+constexpr int kConvCout[13] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+constexpr bool kConvPool[13] = {false, true, false, true, false, false, true, false, false, true, false, false, true};
+
+}  // namespace
+
+struct va_vgg16 {
+    va_ctx* ctx;
+    int c_in, c_in_pad, n_classes, desc_dim;
+    ConvLayer conv[13];
+    float* fcw[4];
+    float* fcb[4];
+    int fc_in[4], fc_out[4];
+    float* in_mean;  // device [c_in] or NULL
+    float* in_std;
+};
+
+namespace {
+
+void pick_brick(int W, int H, int B, int& lgTW, int& lgTH, int& TB)
+{
+    // 128 pixels = TW x TH x TB, powers of two, TW,TH >= 2: maximise the fraction of real pixels.
+    double best = -1.0;
+    for (int lw = 1; lw <= 5; ++lw)
+        for (int lh = 1; lw + lh <= 7; ++lh) {
+            const int tw = 1 << lw, th = 1 << lh, tb = 128 / (tw * th);
+            const double cover = (double)va_cdiv(W, tw) * tw * va_cdiv(H, th) * th * (double)va_cdiv(B, tb) * tb;
+            double util = (double)W * H * B / cover;
+            util += 1e-3 * lw;  // tie-break: wider bricks (longer contiguous runs in x)
+            if (util > best) {
+                best = util;
+                lgTW = lw;
+                lgTH = lh;
+                TB = tb;
+            }
+        }
+}
+
+int launch_conv(const ConvLayer& L, const float* in, float* out, int B, hipStream_t st)
+{
+    ConvArgs a{};
+    a.in = in;
+    a.wp = L.wp;
+    a.bias = L.bias;
+    a.out = out;
+    a.B = B;
+    a.H = a.W = L.hw;
+    a.Cin = L.cin_pad;
+    a.Cout = L.cout;
+    pick_brick(L.hw, L.hw, B, a.lgTW, a.lgTH, a.TB);
+    a.tiles_x = va_cdiv(L.hw, 1 << a.lgTW);
+    a.tiles_y = va_cdiv(L.hw, 1 << a.lgTH);
+    const int tiles_b = va_cdiv(B, a.TB);
+    if (L.cout % 128 == 0) {
+        a.tiles_n = L.cout / 128;
+        const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
+        if (L.pool) k_conv3x3_mfma<2, 2, 2, 2, true><<<grid, 256, 0, st>>>(a);
+        else k_conv3x3_mfma<2, 2, 2, 2, false><<<grid, 256, 0, st>>>(a);
+    } else {
+        a.tiles_n = L.cout / 64;
+        const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
+        if (L.pool) k_conv3x3_mfma<2, 2, 2, 1, true><<<grid, 256, 0, st>>>(a);
+        else k_conv3x3_mfma<2, 2, 2, 1, false><<<grid, 256, 0, st>>>(a);
+    }
+    VA_LAUNCH_CHECK();
+    return VA_OK;
+}
+
+struct FcPlan {
+    int S, kchunk, Npad, Mtiles;
+    size_t slab_floats;
+};
+
+FcPlan plan_fc(int M, int N, int K)
+{
+    FcPlan p;
+    p.Npad = va_cdiv(N, 128) * 128;
+    p.Mtiles = va_cdiv(M, 32);
+    const int ntiles = p.Npad / 128;
+    // aim for >= ~512 workgroups, K slices multiples of 16, at least 256 deep
+    int S = va_cdiv(512, ntiles * p.Mtiles);
+    int maxS = K / 256;
+    if (maxS < 1) maxS = 1;
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    p.kchunk = va_cdiv(va_cdiv(K, S), kBK) * kBK;
+    p.S = va_cdiv(K, p.kchunk);
+    p.slab_floats = (size_t)p.S * p.Mtiles * 32 * p.Npad;
+    return p;
+}
+
+int launch_fc(const float* A, const float* Wt, const float* bias, float* out, float* slab, int M, int N, int K,
+              bool relu, hipStream_t st)
+{
+    const FcPlan p = plan_fc(M, N, K);
+    FcArgs a{};
+    a.A = A;
+    a.Wt = Wt;
+    a.slab = slab;
+    a.M = M;
+    a.N = N;
+    a.K = K;
+    a.S = p.S;
+    a.kchunk = p.kchunk;
+    a.Npad = p.Npad;
+    const dim3 grid((unsigned)((p.Npad / 128) * p.S), (unsigned)p.Mtiles);
+    k_fc_splitk<<<grid, 256, 0, st>>>(a);
+    k_fc_reduce<<<va_cdiv(M * N, 256), 256, 0, st>>>(slab, bias, out, M, N, p.Npad, p.Mtiles * 32, p.S, relu ? 1 : 0);
+    VA_LAUNCH_CHECK();
+    return VA_OK;
+}
+
+struct WsPlan {
+    size_t off_act[2], off_slab, off_fc[2], total;
+};
+
+WsPlan plan_ws(const va_vgg16* m, int B)
+{
+    WsPlan w;
+    size_t off = 0;
+    const size_t act = va_align_up((size_t)B * 224 * 224 * 64 * sizeof(float), 256);
+    w.off_act[0] = off; off += act;
+    w.off_act[1] = off; off += act;
+    size_t slab = 0;
+    for (int i = 0; i < 4; ++i) {
+        const FcPlan p = plan_fc(B, m->fc_out[i], m->fc_in[i]);
+        if (p.slab_floats > slab) slab = p.slab_floats;
+    }
+    w.off_slab = off; off += va_align_up(slab * sizeof(float), 256);
+    const size_t fc = va_align_up((size_t)B * 4096 * sizeof(float), 256);
+    w.off_fc[0] = off; off += fc;
+    w.off_fc[1] = off; off += fc;
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_dim, int dtype,
+                               const void* const* conv_w, const void* const* conv_b, const void* const* fc_w,
+                               const void* const* fc_b, const float* in_mean, const float* in_std, void* stream,
+                               va_vgg16** out)
+{
+    VA_CHECK_ARG(ctx != nullptr && out != nullptr, "va_vgg16_create: NULL ctx/out");
+    *out = nullptr;
+    VA_CHECK_ARG(c_in >= 1 && c_in <= 64, "va_vgg16_create: c_in %d out of range [1,64]", c_in);
+    VA_CHECK_ARG(n_classes >= 1 && n_classes <= 4096 && desc_dim >= 16 && desc_dim <= 4096 && desc_dim % 16 == 0,
+                 "va_vgg16_create: n_classes %d / desc_dim %d unsupported (desc_dim must be a multiple of 16)", n_classes, desc_dim);
+    VA_CHECK_ARG(dtype == VA_DTYPE_F32, "va_vgg16_create: only VA_DTYPE_F32 is implemented");
+    VA_CHECK_ARG(conv_w && conv_b && fc_w && fc_b, "va_vgg16_create: NULL weight tables");
+    for (int i = 0; i < 13; ++i) VA_CHECK_ARG(conv_w[i] && conv_b[i], "va_vgg16_create: conv layer %d weight/bias is NULL", i);
+    for (int i = 0; i < 4; ++i) VA_CHECK_ARG(fc_w[i] && fc_b[i], "va_vgg16_create: fc layer %d weight/bias is NULL", i);
+    hipStream_t st = (hipStream_t)stream;
+    va_vgg16* m = new va_vgg16();
+    memset(m, 0, sizeof(*m));
+    m->ctx = ctx;
+    m->c_in = c_in;
+    m->c_in_pad = va_cdiv(c_in, 16) * 16;
+    m->n_classes = n_classes;
+    m->desc_dim = desc_dim;
+    int hw = 224, cin = c_in, cin_pad = m->c_in_pad;
+    int rc = VA_OK;
+    auto fail = [&](int code) { va_vgg16_destroy(m); return code; };
+    for (int i = 0; i < 13; ++i) {
+        ConvLayer& L = m->conv[i];
+        L.cin = cin;
+        L.cin_pad = cin_pad;
+        L.cout = kConvCout[i];
+        L.hw = hw;
+        L.pool = kConvPool[i];
+        const size_t nw = (size_t)L.cout * 9 * L.cin_pad;
+        if (hipMalloc(&L.wp, nw * sizeof(float)) != hipSuccess || hipMalloc(&L.bias, L.cout * sizeof(float)) != hipSuccess) {
+            va_set_error("va_vgg16_create: hipMalloc failed for conv layer %d", i);
+            return fail(VA_ERR_HIP);
+        }
+        k_pack_conv_w<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>((const float*)conv_w[i], L.wp, L.cout, L.cin, L.cin_pad);
+        if (hipMemcpyAsync(L.bias, conv_b[i], L.cout * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = VA_ERR_HIP;
+        cin = cin_pad = L.cout;
+        if (L.pool) hw /= 2;
+    }
+    const int fin[4] = {512 * 7 * 7, 4096, 4096, desc_dim};
+    const int fout[4] = {4096, 4096, desc_dim, n_classes};
+    for (int i = 0; i < 4; ++i) {
+        m->fc_in[i] = fin[i];
+        m->fc_out[i] = fout[i];
+        const size_t nw = (size_t)fin[i] * fout[i];
+        if (hipMalloc(&m->fcw[i], nw * sizeof(float)) != hipSuccess || hipMalloc(&m->fcb[i], fout[i] * sizeof(float)) != hipSuccess) {
+            va_set_error("va_vgg16_create: hipMalloc failed for fc layer %d", i);
+            return fail(VA_ERR_HIP);
+        }
+        if (i == 0) k_pack_fc1<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>((const float*)fc_w[0], m->fcw[0], fout[0], 512, 49);
+        else if (hipMemcpyAsync(m->fcw[i], fc_w[i], nw * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = VA_ERR_HIP;
+        if (hipMemcpyAsync(m->fcb[i], fc_b[i], fout[i] * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = VA_ERR_HIP;
+    }
+    if (in_mean && in_std) {
+        if (hipMalloc(&m->in_mean, c_in * sizeof(float)) != hipSuccess || hipMalloc(&m->in_std, c_in * sizeof(float)) != hipSuccess) {
+            va_set_error("va_vgg16_create: hipMalloc failed for input normalisation");
+            return fail(VA_ERR_HIP);
+        }
+        if (hipMemcpyAsync(m->in_mean, in_mean, c_in * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) rc = VA_ERR_HIP;
+        if (hipMemcpyAsync(m->in_std, in_std, c_in * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) rc = VA_ERR_HIP;
+    }
+    if (hipGetLastError() != hipSuccess) rc = VA_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) rc = VA_ERR_HIP;
+    if (rc != VA_OK) {
+        va_set_error("va_vgg16_create: HIP failure while packing weights");
+        return fail(rc);
+    }
+    *out = m;
+    return VA_OK;
+}
+
+extern "C" void va_vgg16_destroy(va_vgg16* m)
+{
+    if (!m) return;
+    for (int i = 0; i < 13; ++i) {
+        if (m->conv[i].wp) hipFree(m->conv[i].wp);
+        if (m->conv[i].bias) hipFree(m->conv[i].bias);
+    }
+    for (int i = 0; i < 4; ++i) {
+        if (m->fcw[i]) hipFree(m->fcw[i]);
+        if (m->fcb[i]) hipFree(m->fcb[i]);
+    }
+    if (m->in_mean) hipFree(m->in_mean);
+    if (m->in_std) hipFree(m->in_std);
+    delete m;
+}
+
+extern "C" size_t va_vgg16_workspace_bytes(const va_vgg16* m, int batch)
+{
+    if (!m || batch < 1 || batch > 4096) return 0;
+    return plan_ws(m, batch).total;
+}
+
+extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int batch, void* feat, void* desc, void* logits,
+                                void* workspace, size_t workspace_bytes, void* stream)
+{
+    VA_CHECK_ARG(m != nullptr, "va_vgg16_forward: model is NULL");
+    VA_CHECK_ARG(x != nullptr && workspace != nullptr, "va_vgg16_forward: NULL input/workspace");
+    VA_CHECK_ARG(batch >= 1 && batch <= 4096, "va_vgg16_forward: batch %d out of range [1,4096]", batch);
+    VA_CHECK_ARG(!x_is_u8 || (m->in_mean && m->in_std), "va_vgg16_forward: u8 input needs in_mean/in_std at create time");
+    VA_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "va_vgg16_forward: workspace must be 256-byte aligned");
+    const WsPlan wp = plan_ws(m, batch);
+    if (workspace_bytes < wp.total) {
+        va_set_error("va_vgg16_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, wp.total);
+        return VA_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* act[2] = {(float*)(ws + wp.off_act[0]), (float*)(ws + wp.off_act[1])};
+    float* slab = (float*)(ws + wp.off_slab);
+    float* fcbuf[2] = {(float*)(ws + wp.off_fc[0]), (float*)(ws + wp.off_fc[1])};
+    const int B = batch, HW0 = 224 * 224;
+    {
+        const size_t n = (size_t)B * HW0;
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        if (x_is_u8)
+            k_nchw_to_nhwc_pad<unsigned char><<<grid, 256, 0, st>>>((const unsigned char*)x, act[1], B, m->c_in, HW0, m->c_in_pad, m->in_mean, m->in_std);
+        else
+            k_nchw_to_nhwc_pad<float><<<grid, 256, 0, st>>>((const float*)x, act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
+        VA_LAUNCH_CHECK();
+    }
+    int cur = 1;
+    for (int i = 0; i < 13; ++i) {
+        if (int rc = launch_conv(m->conv[i], act[cur], act[cur ^ 1], B, st)) return rc;
+        cur ^= 1;
+    }
+    const float* f = act[cur];  // NHWC [B][7][7][512]
+    if (feat) {
+        const size_t n = (size_t)B * 512 * 49;
+        k_nhwc_to_nchw<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(f, (float*)feat, B, 512, 49);
+        VA_LAUNCH_CHECK();
+    }
+    if (desc || logits) {
+        if (int rc = launch_fc(f, m->fcw[0], m->fcb[0], fcbuf[0], slab, B, 4096, 512 * 49, true, st)) return rc;
+        if (int rc = launch_fc(fcbuf[0], m->fcw[1], m->fcb[1], fcbuf[1], slab, B, 4096, 4096, true, st)) return rc;
+        float* d = desc ? (float*)desc : fcbuf[0];
+        if (int rc = launch_fc(fcbuf[1], m->fcw[2], m->fcb[2], d, slab, B, m->desc_dim, 4096, true, st)) return rc;
+        if (logits)
+            if (int rc = launch_fc(d, m->fcw[3], m->fcb[3], (float*)logits, slab, B, m->n_classes, m->desc_dim, false, st)) return rc;
+    }
+    return VA_OK;
+}
+
+extern "C" int va_copy_first_layer(va_ctx* ctx, const void* w_rgb, int cout, int n_in, void* w_out, void* stream)
+{
+    VA_CHECK_ARG(ctx != nullptr && w_rgb != nullptr && w_out != nullptr, "va_copy_first_layer: NULL argument");
+    VA_CHECK_ARG(cout >= 1 && n_in >= 1 && (long)cout * n_in * 9 < (1L << 30), "va_copy_first_layer: bad shape");
+    const int n = cout * n_in * 9;
+    k_copy_first_layer<<<va_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>((const float*)w_rgb, (float*)w_out, cout, n_in);
+    VA_LAUNCH_CHECK();
+    return VA_OK;
+}
+
+extern "C" int va_validate_batch(va_ctx* ctx, const void* logits, const void* labels, int batch, int n_classes, void* out,
+                                 void* stream)
+{
+    VA_CHECK_ARG(ctx != nullptr && logits != nullptr && labels != nullptr && out != nullptr, "va_validate_batch: NULL argument");
+    VA_CHECK_ARG(batch >= 1 && n_classes >= 1, "va_validate_batch: bad shape");
+    k_validate_batch<<<1, 256, 0, (hipStream_t)stream>>>((const float*)logits, (const long long*)labels, batch, n_classes, (float*)out);
+    VA_LAUNCH_CHECK();
+    return VA_OK;
+}

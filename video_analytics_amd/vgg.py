@@ -1,0 +1,138 @@
+"""Packed VGG-16 stream model on MI355X: host wrapper over ``va_vgg16_*`` (include/va.h).
+
+This is the object the reference obtains from ``models.vgg16(pretrained=True)`` plus
+``__swapClassifier__`` (and ``__copyFirstLayer__`` for the temporal stream):
+Sheet03/spatialModel.py:110-113,136-152; Sheet03/temporalModel.py:122-126,149-181.
+"""
+import ctypes
+
+import torch
+
+from . import _ffi
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, "vgg")
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        _ws_cache[key] = t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return t
+
+
+def release_workspaces():
+    _ws_cache.clear()
+
+
+def copy_first_layer(w_rgb, n_in):
+    """``__copyFirstLayer__`` (Sheet03/temporalModel.py:149-162) on the device: mean of the three RGB
+    input-channel slices of ``w_rgb [Cout,3,3,3]`` replicated over ``n_in`` input channels."""
+    if not w_rgb.is_cuda or w_rgb.dtype != torch.float32 or w_rgb.dim() != 4 or tuple(w_rgb.shape[1:]) != (3, 3, 3):
+        raise ValueError("copy_first_layer: w_rgb must be a CUDA float32 tensor [Cout,3,3,3]")
+    w_rgb = w_rgb.contiguous()
+    out = torch.empty((w_rgb.shape[0], n_in, 3, 3), dtype=torch.float32, device=w_rgb.device)
+    _ffi.check(_ffi.lib().va_copy_first_layer(_ffi.ctx(w_rgb.device.index), _ffi.ptr(w_rgb), w_rgb.shape[0], n_in,
+                                              _ffi.ptr(out), _ffi.stream_ptr()))
+    return out
+
+
+class Vgg16Stream(object):
+    """VGG-16 'D' features + Linear(25088,4096)/ReLU/Linear(4096,4096)/ReLU/Linear(4096,D)/ReLU/
+    Linear(D,nClasses), weights packed once for the gfx950 kernels."""
+
+    def __init__(self, conv_w, conv_b, fc_w, fc_b, n_classes, desc_dim, in_mean=None, in_std=None, device=None):
+        if len(conv_w) != 13 or len(conv_b) != 13 or len(fc_w) != 4 or len(fc_b) != 4:
+            raise ValueError("Vgg16Stream: need 13 conv and 4 fc weight/bias tensors")
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.device = dev
+        self.c_in = int(conv_w[0].shape[1])
+        self.n_classes = int(n_classes)
+        self.desc_dim = int(desc_dim)
+        cin = self.c_in
+        for i, (w, b) in enumerate(zip(conv_w, conv_b)):
+            co = _ffi_conv_cout(i)
+            if tuple(w.shape) != (co, cin, 3, 3) or tuple(b.shape) != (co,):
+                raise ValueError("Vgg16Stream: conv layer %d has shape %s / %s, expected %s / %s"
+                                 % (i, tuple(w.shape), tuple(b.shape), (co, cin, 3, 3), (co,)))
+            cin = co
+        fshapes = [(4096, 512 * 7 * 7), (4096, 4096), (self.desc_dim, 4096), (self.n_classes, self.desc_dim)]
+        for i, (w, b) in enumerate(zip(fc_w, fc_b)):
+            if tuple(w.shape) != fshapes[i] or tuple(b.shape) != (fshapes[i][0],):
+                raise ValueError("Vgg16Stream: fc layer %d has shape %s, expected %s" % (i, tuple(w.shape), fshapes[i]))
+        keep = []
+
+        def dev_f32(t):
+            t = t.to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        arr = ctypes.c_void_p * 13
+        arr4 = ctypes.c_void_p * 4
+        cw = arr(*[dev_f32(t) for t in conv_w])
+        cb = arr(*[dev_f32(t) for t in conv_b])
+        fw = arr4(*[dev_f32(t) for t in fc_w])
+        fb = arr4(*[dev_f32(t) for t in fc_b])
+        mean = std = None
+        if in_mean is not None and in_std is not None:
+            if len(in_mean) != self.c_in or len(in_std) != self.c_in:
+                raise ValueError("Vgg16Stream: in_mean/in_std need %d entries" % self.c_in)
+            mean = (ctypes.c_float * self.c_in)(*[float(v) for v in in_mean])
+            std = (ctypes.c_float * self.c_in)(*[float(v) for v in in_std])
+        h = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            _ffi.check(_ffi.lib().va_vgg16_create(_ffi.ctx(dev.index), self.c_in, self.n_classes, self.desc_dim, 0,
+                                                  cw, cb, fw, fb, mean, std, _ffi.stream_ptr(), ctypes.byref(h)))
+        self._h = h
+        del keep
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _ffi.lib().va_vgg16_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, x, want_feat=False):
+        """x: CUDA float32 (already normalised) or uint8 ``[B,C,224,224]`` NCHW.
+        Returns (feat [B,512,7,7] or None, descriptor [B,D], logits [B,nClasses])."""
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise ValueError("Vgg16Stream.forward: x must be a CUDA tensor")
+        if x.dim() != 4 or tuple(x.shape[1:]) != (self.c_in, 224, 224):
+            raise ValueError("Vgg16Stream.forward: x must be [B,%d,224,224], got %s" % (self.c_in, tuple(x.shape)))
+        if x.dtype not in (torch.float32, torch.uint8):
+            raise ValueError("Vgg16Stream.forward: x must be float32 or uint8")
+        x = x.contiguous()
+        B = x.shape[0]
+        L = _ffi.lib()
+        nbytes = L.va_vgg16_workspace_bytes(self._h, B)
+        ws = _workspace(nbytes, x.device)
+        feat = torch.empty((B, 512, 7, 7), dtype=torch.float32, device=x.device) if want_feat else None
+        desc = torch.empty((B, self.desc_dim), dtype=torch.float32, device=x.device)
+        logits = torch.empty((B, self.n_classes), dtype=torch.float32, device=x.device)
+        _ffi.check(L.va_vgg16_forward(self._h, _ffi.ptr(x), int(x.dtype == torch.uint8), B, _ffi.ptr(feat),
+                                      _ffi.ptr(desc), _ffi.ptr(logits), _ffi.ptr(ws), ws.numel(), _ffi.stream_ptr()))
+        return feat, desc, logits
+
+
+def _ffi_conv_cout(i):
+    return (64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512)[i]
+
+
+def validate_batch(logits, labels):
+    """(mean cross-entropy, number correct) of one batch on the device
+    (Sheet03/spatialModel.py:219-221); returns a CUDA float32 tensor [2] without synchronising."""
+    if not logits.is_cuda or logits.dtype != torch.float32 or logits.dim() != 2:
+        raise ValueError("validate_batch: logits must be CUDA float32 [B,C]")
+    labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
+    if labels.dim() != 1 or labels.shape[0] != logits.shape[0]:
+        raise ValueError("validate_batch: labels must be [B]")
+    logits = logits.contiguous()
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    _ffi.check(_ffi.lib().va_validate_batch(_ffi.ctx(logits.device.index), _ffi.ptr(logits), _ffi.ptr(labels),
+                                            logits.shape[0], logits.shape[1], _ffi.ptr(out), _ffi.stream_ptr()))
+    return out
