@@ -49,6 +49,13 @@ def lib():
         raise RuntimeError(
             "libva_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the hot path)" % LIB_PATH)
+    # The library shares ONE HIP runtime with torch (streams and device pointers cross the ABI):
+    # torch's bundled libamdhip64.so (SONAME libamdhip64.so.7) must be in the process before ours
+    # is resolved, or the system copy under /opt/rocm would be loaded as a second runtime.
+    import torch
+    hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip_rt):
+        ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
     L = ctypes.CDLL(LIB_PATH)
     vp, ci, cf, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
     pp = ctypes.POINTER(ctypes.c_void_p)

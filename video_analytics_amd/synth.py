@@ -26,26 +26,60 @@ def _mix32(x):
     return x
 
 
+_M32 = 0xFFFFFFFF
+
+
+def _mix32_t(x):
+    """The same hash on int64 torch tensors holding uint32 values (any device)."""
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & _M32
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & _M32
+    x = x ^ (x >> 16)
+    return x
+
+
+def _keys(seed, stream):
+    key = int(_mix32(np.array([(seed * 0x9E3779B1 + stream * 0x85EBCA77 + 0x1234567) & _M32], dtype=np.uint32))[0])
+    key2 = int(_mix32(np.array([(key + 0x68E31DA4) & _M32], dtype=np.uint32))[0])
+    return key, key2
+
+
 def hash_uniform(seed, stream, n, chunk=1 << 24):
-    """float32[n] in [0,1): element i = 24 high bits of mix(mix(i ^ key) + key2)."""
-    key = _mix32(np.array([(seed * 0x9E3779B1 + stream * 0x85EBCA77 + 0x1234567) & 0xFFFFFFFF], dtype=np.uint32))[0]
-    key2 = _mix32(np.array([(int(key) + 0x68E31DA4) & 0xFFFFFFFF], dtype=np.uint32))[0]
+    """float32[n] in [0,1): element i = 24 high bits of mix(mix(i ^ key) + key2)  (numpy, CPU)."""
+    key, key2 = _keys(seed, stream)
     out = np.empty(n, dtype=np.float32)
     for s in range(0, n, chunk):
         e = min(n, s + chunk)
         i = np.arange(s, e, dtype=np.uint32)
-        h = _mix32(_mix32(i ^ key) + key2)
+        h = _mix32(_mix32(i ^ np.uint32(key)) + np.uint32(key2))
         out[s:e] = (h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
     return out
 
 
-def _uniform_pm(seed, stream, shape, bound):
+def hash_uniform_t(seed, stream, n, device="cpu", chunk=1 << 24):
+    """Bit-identical to ``hash_uniform`` but computed with torch integer ops on ``device``."""
+    key, key2 = _keys(seed, stream)
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        i = torch.arange(s, e, dtype=torch.int64, device=device)
+        h = _mix32_t((_mix32_t(i ^ key) + key2) & _M32)
+        out[s:e] = (h >> 8).to(torch.float32) * (1.0 / 16777216.0)
+    return out
+
+
+def _uniform_pm(seed, stream, shape, bound, device="cpu"):
     n = int(np.prod(shape))
-    u = hash_uniform(seed, stream, n)
-    return torch.from_numpy(((u * np.float32(2.0) - np.float32(1.0)) * np.float32(bound)).reshape(shape))
+    b = float(np.float32(bound))
+    if str(device) == "cpu":
+        u = hash_uniform(seed, stream, n)
+        return torch.from_numpy(((u * np.float32(2.0) - np.float32(1.0)) * np.float32(b)).reshape(shape))
+    u = hash_uniform_t(seed, stream, n, device=device)
+    return ((u * 2.0 - 1.0) * b).reshape(shape)
 
 
-def synth_vgg16_weights(c_in=3, n_classes=101, desc_dim=256, seed=1):
+def synth_vgg16_weights(c_in=3, n_classes=101, desc_dim=256, seed=1, device="cpu"):
     """Random-init weights of the reference's architecture (Sheet03/spatialModel.py:110,136-152).
 
     Kaiming-uniform (bound sqrt(6/fan_in)) keeps activations O(1) through 13 conv + 4 FC layers so
@@ -59,12 +93,12 @@ def synth_vgg16_weights(c_in=3, n_classes=101, desc_dim=256, seed=1):
     sid = 0
     for li, (ci, co) in enumerate(VGG16_CONVS):
         fan_in = ci * 9
-        conv_w.append(_uniform_pm(seed, sid, (co, ci, 3, 3), math.sqrt(6.0 / fan_in))); sid += 1
+        conv_w.append(_uniform_pm(seed, sid, (co, ci, 3, 3), math.sqrt(6.0 / fan_in), device)); sid += 1
         bfan = (c_in * 9) if li == 0 else fan_in
-        conv_b.append(_uniform_pm(seed, sid, (co,), 1.0 / math.sqrt(bfan))); sid += 1
+        conv_b.append(_uniform_pm(seed, sid, (co,), 1.0 / math.sqrt(bfan), device)); sid += 1
     for (fi, fo) in [(512 * 7 * 7, 4096), (4096, 4096), (4096, desc_dim), (desc_dim, n_classes)]:
-        fc_w.append(_uniform_pm(seed, sid, (fo, fi), math.sqrt(6.0 / fi))); sid += 1
-        fc_b.append(_uniform_pm(seed, sid, (fo,), 1.0 / math.sqrt(fi))); sid += 1
+        fc_w.append(_uniform_pm(seed, sid, (fo, fi), math.sqrt(6.0 / fi), device)); sid += 1
+        fc_b.append(_uniform_pm(seed, sid, (fo,), 1.0 / math.sqrt(fi), device)); sid += 1
     return dict(conv_w=conv_w, conv_b=conv_b, fc_w=fc_w, fc_b=fc_b)
 
 
