@@ -6,7 +6,8 @@
  * is reached through three Python call surfaces.  Each entry point
  * below names the reference interface it stands behind:
  *
- *   va_vgg16_*        self.features(ip) + the classifierList traversal inside validate():
+ *   va_vgg16_*        self.features(ip) (forward with only `feat` requested) + the classifierList
+ *                     traversal (va_vgg16_classify) inside validate():
  *                     Sheet03/spatialModel.py:110-113,127-129,136-152,212-218 and the
  *                     temporal twin Sheet03/temporalModel.py:122-126,140-142,165-181,241-247.
  *   va_copy_first_layer   TemporalNetwork.__copyFirstLayer__: Sheet03/temporalModel.py:149-162.
@@ -83,6 +84,14 @@ size_t va_vgg16_workspace_bytes(const va_vgg16* model, int batch);
 int va_vgg16_forward(va_vgg16* model, const void* x, int x_is_u8, int batch,
                      void* feat, void* desc, void* logits,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * The classifier traversal alone (Sheet03/spatialModel.py:213-218): feat f32 [batch][512][7][7]
+ * NCHW (as returned through `feat` above; flattened CHW-major) -> desc / logits (either may be
+ * NULL).  va_vgg16_forward(x) == va_vgg16_classify(features(x)).
+ */
+int va_vgg16_classify(va_vgg16* model, const void* feat, int batch, void* desc, void* logits,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* w_rgb f32 [cout][3][3][3] -> w_out f32 [cout][n_in][3][3]: mean over the 3 input channels,
  * accumulated in channel order then divided by 3, replicated n_in times. */

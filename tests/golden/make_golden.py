@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors under tests/golden/ (run once, in the build container):
+
+    python tests/golden/make_golden.py
+
+  * tvl1_64x48.npz   frames + flows of the C oracle (oracle/tvl1_oracle.c) in fixed-iteration and
+                     stopping-rule mode, and the quantised flow volume.  PARITY UNPINNED against the
+                     reference (it has no TV-L1): these pin the oracle and the HIP path to each other
+                     and to history.
+  * vgg_small.npz    class scores / descriptors / per-layer fp64 checksums of the torch-CPU oracle
+                     (oracle/vgg_oracle.py) for both streams on 4 synthetic clips with the synthetic
+                     weights of video_analytics_amd/synth.py (seeds 1 and 2).
+  * demoTest.txt / demoTrain.txt are the reference's own video lists (data fixtures, copied
+    verbatim from /root/reference/Sheet03/).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import tvl1_oracle, vgg_oracle  # noqa: E402
+from video_analytics_amd import synth  # noqa: E402
+
+
+def tvl1():
+    _, gray, _ = synth.synth_clips(2, seed=21, H=48, W=64, n_gray=3)
+    g = gray.numpy()
+    fixed = tvl1_oracle.tvl1_flow(g, tvl1_oracle.default_params(epsilon=0.0, iters=30, warps=3))
+    eps, iters = tvl1_oracle.tvl1_flow(g, tvl1_oracle.default_params(epsilon=0.01, iters=300), return_iters=True)
+    stack = tvl1_oracle.flow_to_stack(fixed)
+    np.savez_compressed(os.path.join(HERE, "tvl1_64x48.npz"), gray=g, flow_fixed=fixed, flow_eps=eps, iters_eps=iters,
+                        stack_fixed=stack)
+    print("tvl1: eps-mode iterations", iters, "max |flow|", np.abs(fixed).max())
+
+
+def layer_checksums(x, conv_w, conv_b):
+    """fp64 sum of every conv block's output (after ReLU / pool), for localising a wrong layer."""
+    import torch.nn.functional as F
+    out = []
+    i = 0
+    x = x.double()
+    for v in vgg_oracle.VGG16_CFG:
+        if v == "M":
+            x = F.max_pool2d(x, 2, 2)
+            out[-1] = float(x.sum())
+        else:
+            x = F.relu(F.conv2d(x, conv_w[i].double(), conv_b[i].double(), padding=1))
+            out.append(float(x.sum()))
+            i += 1
+    return np.array(out)
+
+
+def vgg():
+    res = {}
+    for name, c_in, seed in (("s", 3, 1), ("t", 20, 2)):
+        w = synth.synth_vgg16_weights(c_in=c_in, seed=seed)
+        if c_in != 3:
+            w["conv_w"][0] = vgg_oracle.copy_first_layer(w["conv_w"][0], c_in)
+        u = synth.hash_uniform(100 + seed, 77, 4 * c_in * 224 * 224).reshape(4, c_in, 224, 224)
+        x = torch.from_numpy(u * 4.0 - 2.0)
+        feat, desc, logits = vgg_oracle.forward(x, w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"])
+        _, desc64, logits64 = vgg_oracle.forward(x[:1], w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], dtype=torch.float64)
+        res["logits_" + name] = logits.numpy()
+        res["desc_" + name] = desc.numpy()
+        res["feat_sum_" + name] = feat.double().sum(dim=(1, 2, 3)).numpy()
+        res["logits64_" + name] = logits64.numpy()
+        res["layersum_" + name] = layer_checksums(x[:1], w["conv_w"], w["conv_b"])
+        print("vgg", name, "max |logit|", float(logits.abs().max()), "fp32-fp64 max diff", float((logits[:1].double() - logits64).abs().max()))
+    np.savez_compressed(os.path.join(HERE, "vgg_small.npz"), **res)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    tvl1()
+    vgg()

@@ -1,0 +1,65 @@
+"""The C-ABI shared library loads on a CPU-only box and exports every symbol include/va.h declares
+(no compute calls: there is no GPU here and no CPU fallback in the library)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__
+    from video_analytics_amd import _ffi
+    if not os.path.exists(_ffi.LIB_PATH):
+        __graft_entry__.build()
+    return _ffi.lib()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from video_analytics_amd import _ffi
+    hdr = open(os.path.join(ROOT, "include", "va.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(va_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_ffi.EXPORTS), declared ^ set(_ffi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.va_version() >= 1
+
+
+def test_host_only_entry_points(lib):
+    from oracle import tvl1_oracle
+    from video_analytics_amd import _ffi
+    p = _ffi.default_tvl1_params()
+    assert (round(p.tau, 4), round(p.lambda_, 4), round(p.theta, 4), p.nscales, p.warps, p.iters) == (0.25, 0.15, 0.3, 5, 5, 300)
+    assert abs(p.epsilon - 0.01) < 1e-9 and abs(p.scale_step - 0.8) < 1e-7 and p.block_iters == 0
+    from video_analytics_amd.flow import pyramid_sizes
+    for (w, h) in [(224, 224), (1280, 720), (320, 240), (64, 48), (17, 300)]:
+        assert pyramid_sizes(w, h) == tvl1_oracle.pyramid_sizes(w, h)
+    assert pyramid_sizes(224, 224) == [(224, 224), (179, 179), (143, 143), (114, 114), (91, 91)]
+    assert sum(a * b for a, b in pyramid_sizes(1280, 720)) == 2285258
+    assert lib.va_tvl1_workspace_bytes(224, 224, 32, 11, ctypes.byref(p)) > 0
+    assert lib.va_tvl1_workspace_bytes(8, 8, 1, 2, ctypes.byref(p)) == 0  # too small: rejected
+    assert b"out of range" in lib.va_last_error()
+
+
+def test_ctx_create_fails_loudly_without_a_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from video_analytics_amd import _ffi, flow
+    with pytest.raises(RuntimeError):
+        _ffi.ctx(0)
+    with pytest.raises((RuntimeError, ValueError)):
+        flow.tvl1_flow(torch.zeros(1, 2, 64, 64, dtype=torch.uint8))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "video_analytics_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), os.path.join(dp, f)

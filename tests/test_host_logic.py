@@ -1,0 +1,182 @@
+"""Host logic of the path (pure Python, CPU): bit-exact known-answer tests derived by hand from the
+reference lines cited in video_analytics_amd/utils.py (the reference ships no tests: SURVEY.md section 4)."""
+import csv
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from video_analytics_amd import utils as U
+from video_analytics_amd import combinedModel, parameters
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_parameters_match_reference_values():
+    # Sheet03/parameters.py:2-21
+    assert parameters.VIDEO_INPUT_FLOW_COUNT == 10 and parameters.SPATIAL_BATCH_SIZE == 60
+    assert parameters.TEMPORAL_BATCH_SIZE == 32 and parameters.NWORKERS_LOADER == 4 and parameters.SHUFFLE_LOADER is True
+    assert parameters.NORM_MEANS_TF == [0.485, 0.456, 0.406] and parameters.NORM_STDS_TF == [0.229, 0.224, 0.225]
+    assert parameters.NACTION_CLASSES == 101 and parameters.VIDEO_DESCRIPTOR_DIM == 256
+    assert parameters.X_PREFIX_FLOW == "flow_x_" and parameters.Y_PREFIX_FLOW == "flow_y_" and parameters.FRAME_EXTN == ".jpg"
+    assert parameters.COLOR_JITTERS == [0, 0, 0, 0] and parameters.CROP_SIZE_TF == 224
+
+
+def test_videoinfo_known_answers_from_the_reference_lists():
+    test_lines = open(os.path.join(GOLD, "demoTest.txt")).readlines()
+    train_lines = open(os.path.join(GOLD, "demoTrain.txt")).readlines()
+    assert len(test_lines) == 951 and len(train_lines) == 2409
+    assert U.videoInfo(test_lines[0], "test") == (
+        "ApplyEyeMakeup/v_ApplyEyeMakeup_g01_c01.avi", "v_ApplyEyeMakeup_g01_c01", None, "ApplyEyeMakeup", "g01", "c01")
+    assert U.videoInfo(test_lines[950], "test") == (
+        "CuttingInKitchen/v_CuttingInKitchen_g07_c04.avi", "v_CuttingInKitchen_g07_c04", None, "CuttingInKitchen", "g07", "c04")
+    assert U.videoInfo(train_lines[0], "train") == (
+        "ApplyEyeMakeup/v_ApplyEyeMakeup_g08_c01.avi", "v_ApplyEyeMakeup_g08_c01", "1", "ApplyEyeMakeup", "g08", "c01")
+    # every line of both lists parses; labels are the raw 1-based indices 1..25 (quirk 4)
+    labels = set()
+    for l in train_lines:
+        labels.add(int(U.videoInfo(l, "train")[2]))
+    assert labels == set(range(1, 26))
+    cats = {U.videoInfo(l, "test")[3] for l in test_lines}
+    assert len(cats) == 25
+
+
+def test_videoinfo_error_behaviour():
+    with pytest.raises(ValueError):
+        U.videoInfo("A/v_A_g01_c01.avi", "train")  # no label: tuple unpacking fails as in the reference
+    with pytest.raises(ValueError):
+        U.videoInfo("A/B/v_A_g01_c01.avi", "test")  # three path parts
+    with pytest.raises(ValueError):
+        U.videoInfo("A/v_A_extra_g01_c01.avi", "test")  # five '_' parts
+
+
+def test_spatial_frame_index_is_inclusive_on_both_ends():
+    random.seed(0)
+    seen = {U.spatialFrameIndex(4) for _ in range(400)}
+    assert seen == {0, 1, 2, 3}
+    assert U.spatialFrameIndex(17, r=16) == 16
+    with pytest.raises(ValueError):
+        U.spatialFrameIndex(0)
+
+
+def test_temporal_flow_indices():
+    # 60 files = 30 flows per axis, L = 10: start in [1, 20]; the last index 30 is never read (quirk 8)
+    random.seed(1)
+    starts = {U.temporalFlowIndices(60, 10)[0] for _ in range(2000)}
+    assert starts == set(range(1, 21))
+    start, order = U.temporalFlowIndices(60, 10, r=7)
+    assert start == 7 and len(order) == 20
+    assert order[:4] == [("x", 7), ("y", 7), ("x", 8), ("y", 8)] and order[-1] == ("y", 16)
+    assert U.flowFileName("flow_x_", 7) == "flow_x_0007.jpg" and U.flowFileName("flow_y_", 123) == "flow_y_0123.jpg"
+    with pytest.raises(ValueError):
+        U.temporalFlowIndices(61, 10)  # odd file count: non-integral float bound in py2's randint
+    with pytest.raises(ValueError):
+        U.temporalFlowIndices(20, 10)  # nFlows - L = 0: empty range
+
+
+def test_transform_random_draw_order_and_ranges():
+    img = np.arange(240 * 320 * 3, dtype=np.uint32).reshape(240, 320, 3).astype(np.uint8)
+    random.seed(5)
+    i, j, f = random.randint(0, 16), random.randint(0, 96), random.random()
+    random.seed(5)
+    out = U.Compose([U.RandomCrop(224), U.RandomHorizontalFlip()])(img)
+    ref = img[i:i + 224, j:j + 224]
+    if f < 0.5:
+        ref = ref[:, ::-1]
+    assert np.array_equal(out, ref)
+    # UCF frames are 320x240: crop offsets top in [0,16], left in [0,96]
+    random.seed(0)
+    tops, lefts = set(), set()
+    for _ in range(3000):
+        s = random.getstate()
+        tops.add(random.randint(0, 16)); lefts.add(random.randint(0, 96))
+        random.setstate(s)
+        U.RandomCrop(224)(img)
+    assert tops == set(range(17)) and max(lefts) == 96 and min(lefts) == 0
+
+
+def test_totensor_normalize_three_channel_and_single_channel_rule():
+    img = np.array([[[0, 128, 255]]], dtype=np.uint8)  # 1x1 RGB
+    t = U.Compose([U.ToTensor(), U.Normalize(parameters.NORM_MEANS_TF, parameters.NORM_STDS_TF)])(img)
+    exp = [(0 / 255 - 0.485) / 0.229, (128 / 255 - 0.456) / 0.224, (255 / 255 - 0.406) / 0.225]
+    assert t.shape == (3, 1, 1) and np.allclose(t.flatten().numpy(), exp, atol=1e-6)
+    g = np.array([[100]], dtype=np.uint8)  # 'L' flow image: only the first mean/std pair applies
+    t1 = U.Compose([U.ToTensor(), U.Normalize(parameters.NORM_MEANS_TF, parameters.NORM_STDS_TF)])(g)
+    assert t1.shape == (1, 1, 1) and abs(float(t1) - (100 / 255 - 0.485) / 0.229) < 1e-6
+
+
+def test_gettransforms_uses_literal_224_and_identity_jitter():
+    tf = U.getTransforms(cropSize=100)
+    assert isinstance(tf.transforms[0], U.RandomCrop) and tf.transforms[0].size == (224, 224)
+    random.seed(3)
+    out = tf(np.zeros((240, 320, 3), dtype=np.uint8))
+    assert out.shape == (3, 224, 224) and out.dtype == torch.float32
+    with pytest.raises(ValueError):
+        tf(np.zeros((100, 100, 3), dtype=np.uint8))
+
+
+def test_average_meter_and_descriptor_csv(tmp_path):
+    m = U.AverageMeter()
+    m.update(torch.tensor([1.0, 3.0])); m.update(torch.tensor([3.0, 5.0]))
+    assert m.count == 2 and torch.equal(m.avg, torch.tensor([2.0, 4.0]))
+    d = {"v_A_g01_c01": (U.AverageMeter(), torch.tensor(3)), "v_B_g01_c02": (U.AverageMeter(), torch.tensor(7))}
+    d["v_A_g01_c01"][0].update(torch.arange(256, dtype=torch.float32) * 0.5)
+    d["v_B_g01_c02"][0].update(torch.ones(256))
+    p = str(tmp_path / "desc.csv")
+    U.saveVideoDescriptors(d, p)
+    rows = list(csv.reader(open(p)))
+    assert len(rows) == 2 and len(rows[0]) == 258
+    assert rows[0][0] == "v_A_g01_c01" and rows[0][1] == "3" and float(rows[0][3]) == 0.5
+    assert rows[1][0] == "v_B_g01_c02" and rows[1][1] == "7" and rows[1][2] == "1.0"
+
+
+def _write_csv(path, rows):
+    with open(path, "w") as f:
+        for name, label, val in rows:
+            f.write(name + "," + str(label) + "," + ",".join(repr(float(val + k)) for k in range(256)) + "\n")
+
+
+def test_combine_descriptors_join_order_and_layout(tmp_path):
+    s, t = str(tmp_path / "s.csv"), str(tmp_path / "t.csv")
+    _write_csv(s, [("v_a", 1, 0.0), ("v_b", 2, 1000.0), ("v_c", 3, 2000.0)])
+    _write_csv(t, [("v_c", 3, -2000.0), ("v_a", 1, -1.0), ("v_x", 9, 5.0)])  # different order, one unmatched each
+    X, y = combinedModel.combineDescriptors(s, t)
+    assert X.shape == (2, 512) and list(y) == [1, 3]  # spatial order, inner join, spatial labels
+    assert X[0, 0] == 0.0 and X[0, 255] == 255.0 and X[0, 256] == -1.0 and X[1, 0] == 2000.0 and X[1, 256] == -2000.0
+    W = np.zeros((3, 512)); W[0, 0] = -1.0; W[2, 0] = 1.0
+    pred = combinedModel.linearSvmPredict(X, W, np.zeros(3), np.array([1, 2, 3]))
+    assert list(pred) == [1, 3] and combinedModel.accuracy(pred, y) == 100.0
+
+
+def test_datasets_read_the_reference_directory_layout(tmp_path):
+    from PIL import Image
+    from video_analytics_amd.spatialModel import SpatialDataset
+    from video_analytics_amd.temporalModel import TemporalDataset
+    lst = tmp_path / "list.txt"
+    lst.write_text("Archery/v_Archery_g01_c01.avi\nBiking/v_Biking_g02_c03.avi\n")
+    lab = tmp_path / "classInd.txt"
+    lab.write_text("1 Archery\n2 Biking\n")
+    rng = np.random.default_rng(0)
+    for cat, vid in (("Archery", "v_Archery_g01_c01"), ("Biking", "v_Biking_g02_c03")):
+        fd = tmp_path / "frames" / cat / vid
+        fd.mkdir(parents=True)
+        for i in range(3):
+            Image.fromarray(np.full((240, 320, 3), 40 * i + 10, dtype=np.uint8)).save(str(fd / ("%d.jpg" % i)), quality=100)
+        wd = tmp_path / "flow" / cat / vid
+        wd.mkdir(parents=True)
+        for i in range(1, 14):
+            for ax in ("x", "y"):
+                Image.fromarray(rng.integers(0, 255, (240, 320), dtype=np.uint8), mode="L").save(str(wd / ("flow_%s_%04d.jpg" % (ax, i))))
+    tf = U.getTransforms()
+    random.seed(0)
+    ds = SpatialDataset(str(lst), str(tmp_path / "frames"), tf, mode="test", actionLabelLoc=str(lab))
+    assert len(ds) == 2
+    x, label, name = ds[1]
+    assert x.shape == (3, 224, 224) and label == 2 and name == "v_Biking_g02_c03"
+    dt = TemporalDataset(str(lst), str(tmp_path / "flow"), tf, flowSampleSize=10, mode="test", actionLabelLoc=str(lab))
+    v, label, name = dt[0]
+    assert v.shape == (20, 224, 224) and label == 1 and name == "v_Archery_g01_c01"
+    with pytest.raises(ValueError):
+        SpatialDataset(str(lst), str(tmp_path / "frames"), tf, mode="test")  # no label file: Sheet03/spatialModel.py:46

@@ -1,0 +1,109 @@
+"""Pins of the TV-L1 CPU oracle (oracle/tvl1_oracle.c).  PARITY UNPINNED against the reference: it
+has no TV-L1 code or fixtures.  The pins are (1) analytic known answers of the
+published algorithm, (2) direct numpy restatements of single steps, (3) the committed outputs in
+tests/golden/tvl1_64x48.npz (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _texture(H, W, seed=0, margin=16):
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    big = gaussian_filter(rng.uniform(0, 1, (H + 2 * margin, W + 2 * margin)), 2.0)
+    return (big - big.min()) / (big.max() - big.min()) * 255.0
+
+
+def _shift(big, H, W, dx, dy, margin=16):
+    from scipy.ndimage import map_coordinates
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    return map_coordinates(big, [yy + margin + dy, xx + margin + dx], order=3).astype(np.float32)
+
+
+def test_zero_motion_gives_exactly_zero_flow(oracle_tvl1):
+    big = _texture(64, 80)
+    f = _shift(big, 64, 80, 0, 0)
+    fl = oracle_tvl1.tvl1_flow(np.stack([f, f])[None])
+    assert fl.shape == (1, 2, 64, 80) and np.all(fl == 0.0)
+
+
+@pytest.mark.parametrize("d", [(1.5, -0.75), (-2.0, 1.0)])
+def test_constant_translation_is_recovered(oracle_tvl1, d):
+    H, W = 96, 128
+    big = _texture(H, W, seed=1)
+    f0 = _shift(big, H, W, 0, 0)
+    f1 = _shift(big, H, W, -d[0], -d[1])  # I1(x) = I0(x - d)  =>  flow = d
+    fl = oracle_tvl1.tvl1_flow(np.stack([f0, f1])[None], oracle_tvl1.default_params(epsilon=0.0, iters=100))
+    c = fl[0][:, 16:-16, 16:-16]
+    assert abs(c[0].mean() - d[0]) < 0.02 and abs(c[1].mean() - d[1]) < 0.02
+    assert c[0].std() < 0.05 and c[1].std() < 0.05
+
+
+def test_pyramid_sizes_known_answers(oracle_tvl1):
+    assert oracle_tvl1.pyramid_sizes(224, 224) == [(224, 224), (179, 179), (143, 143), (114, 114), (91, 91)]
+    assert oracle_tvl1.pyramid_sizes(1280, 720) == [(1280, 720), (1024, 576), (819, 461), (655, 369), (524, 295)]
+    assert oracle_tvl1.pyramid_sizes(20, 20) == [(20, 20), (16, 16)]  # stops before min(w,h) < 16
+    assert oracle_tvl1.pyramid_sizes(64, 48, nscales=1) == [(64, 48)]
+
+
+def test_zoom_out_preserves_constants_and_ramps(oracle_tvl1):
+    const = np.full((40, 50), 37.0, dtype=np.float32)
+    out = oracle_tvl1.zoom_out(const)
+    assert out.shape == (32, 40) and np.allclose(out, 37.0, atol=1e-4)
+    ramp = np.tile(np.arange(50, dtype=np.float32), (40, 1))
+    out = oracle_tvl1.zoom_out(ramp)
+    # a linear ramp survives a symmetric smoothing; sampling at x * (50/40)
+    assert np.allclose(out[5, 5:35], np.arange(5, 35) * np.float32(50.0 / 40.0), atol=1e-3)
+
+
+def test_single_iteration_against_numpy_restatement(oracle_tvl1):
+    """One level, one warp, one inner iteration from u = 0, p = 0, restated in float64 numpy."""
+    import ctypes
+    rng = np.random.default_rng(3)
+    H, W = 20, 24
+    I0 = rng.uniform(0, 255, (H, W)).astype(np.float32)
+    I1 = rng.uniform(0, 255, (H, W)).astype(np.float32)
+    Ix = np.empty_like(I1); Iy = np.empty_like(I1)
+    L = oracle_tvl1.lib()
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    L.ora_tvl1_centered_gradient(fp(I1), W, H, fp(Ix), fp(Iy))
+    gx = 0.5 * (I1[:, np.minimum(np.arange(W) + 1, W - 1)] - I1[:, np.maximum(np.arange(W) - 1, 0)])
+    assert np.allclose(Ix, gx, atol=1e-5)
+    u1 = np.zeros((H, W), np.float32); u2 = np.zeros((H, W), np.float32)
+    P = oracle_tvl1.default_params(epsilon=0.0, iters=1, warps=1)
+    n = L.ora_tvl1_level(fp(I0), fp(I1), fp(Ix), fp(Iy), W, H, ctypes.byref(P), fp(u1), fp(u2))
+    assert n == 1
+    # u = 0, p = 0: rho = I1 - I0, u' = clamp(-rho/grad, -l_t, l_t) * grad I1  (div p = 0)
+    l_t = 0.15 * 0.3
+    rho = I1.astype(np.float64) - I0
+    grad = Ix.astype(np.float64) ** 2 + Iy.astype(np.float64) ** 2
+    fi = np.clip(-rho / np.maximum(grad, 1e-30), -l_t, l_t) * (grad >= 1e-10)
+    assert np.allclose(u1, fi * Ix, atol=1e-5) and np.allclose(u2, fi * Iy, atol=1e-5)
+
+
+def test_flow_to_stack_known_answers(oracle_tvl1):
+    fl = np.array([-25.0, -20.0, 0.0, 20.0, 30.0, 0.07843], dtype=np.float32).reshape(1, 2, 1, 3)
+    st = oracle_tvl1.flow_to_stack(fl, bound=20.0, mean=0.485, std=0.229).reshape(-1)
+    q = np.array([0, 0, 128, 255, 255, 128], dtype=np.float64)  # rint(127.5)=128 (half to even), rint(127.99..)=128
+    assert np.allclose(st, (q / 255.0 - 0.485) / 0.229, atol=1e-6)
+
+
+def test_golden_vectors(oracle_tvl1):
+    g = np.load(os.path.join(GOLD, "tvl1_64x48.npz"))
+    fixed = oracle_tvl1.tvl1_flow(g["gray"], oracle_tvl1.default_params(epsilon=0.0, iters=30, warps=3))
+    assert np.array_equal(fixed, g["flow_fixed"])
+    eps, iters = oracle_tvl1.tvl1_flow(g["gray"], oracle_tvl1.default_params(epsilon=0.01, iters=300), return_iters=True)
+    assert np.array_equal(eps, g["flow_eps"]) and np.array_equal(iters, g["iters_eps"])
+    assert np.array_equal(oracle_tvl1.flow_to_stack(fixed), g["stack_fixed"])
+    # thread count does not change results (OpenMP is across pairs only)
+    assert np.array_equal(oracle_tvl1.tvl1_flow(g["gray"], oracle_tvl1.default_params(epsilon=0.0, iters=30, warps=3), nthreads=1), fixed)
+
+
+def test_bad_arguments(oracle_tvl1):
+    with pytest.raises(ValueError):
+        oracle_tvl1.tvl1_flow(np.zeros((1, 1, 32, 32), np.float32))  # a single frame
+    with pytest.raises(ValueError):
+        oracle_tvl1.tvl1_flow(np.zeros((1, 2, 32, 32), np.float32), oracle_tvl1.default_params(scale_step=1.2))

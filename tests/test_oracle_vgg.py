@@ -1,0 +1,76 @@
+"""Pins of the torch-CPU VGG oracle (oracle/vgg_oracle.py): structure known answers derived from the
+reference lines it cites, and the committed goldens (tests/golden/vgg_small.npz)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import vgg_oracle
+from video_analytics_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_layer_list_is_vgg16_d_without_batchnorm():
+    convs = [v for v in vgg_oracle.VGG16_CFG if v != "M"]
+    assert convs == [64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512]
+    assert vgg_oracle.VGG16_CFG.count("M") == 5
+    # 2*MAC per clip of the conv stack: SURVEY.md section 2a (30.693 GFLOP spatial, 31.676 temporal)
+    def gflop(cin):
+        hw, f = 224, 0
+        for v in vgg_oracle.VGG16_CFG:
+            if v == "M":
+                hw //= 2
+            else:
+                f += 2 * hw * hw * v * cin * 9
+                cin = v
+        return f / 1e9
+    assert abs(gflop(3) - 30.693) < 0.01 and abs(gflop(20) - 31.676) < 0.01
+
+
+def test_copy_first_layer_rule():
+    w = torch.arange(2 * 3 * 9, dtype=torch.float32).reshape(2, 3, 3, 3)
+    out = vgg_oracle.copy_first_layer(w, 20)
+    assert out.shape == (2, 20, 3, 3)
+    exp = (w[:, 0] + w[:, 1] + w[:, 2]) / 3
+    for c in range(20):
+        assert torch.equal(out[:, c], exp)
+
+
+def test_flatten_is_chw_major_and_descriptor_is_post_relu():
+    torch.manual_seed(0)
+    feat = torch.randn(2, 512, 7, 7)
+    fc_w = [torch.zeros(4096, 25088), torch.eye(4096), torch.zeros(256, 4096), torch.zeros(101, 256)]
+    fc_b = [torch.zeros(4096), torch.zeros(4096), torch.full((256,), -1.0), torch.arange(101, dtype=torch.float32)]
+    c, h, w = 17, 3, 5
+    fc_w[0][0, c * 49 + h * 7 + w] = 1.0  # picks feat[:, c, h, w] under the reference's view(B,-1)
+    fc_w[2][0, 0] = 1.0
+    desc, logits = vgg_oracle.classifier(feat, fc_w, fc_b)
+    exp = torch.relu(torch.relu(feat[:, c, h, w]) - 1.0)
+    assert torch.allclose(desc[:, 0], exp) and float(desc.min()) >= 0.0
+    assert torch.equal(logits, fc_b[3].expand(2, 101))  # no softmax on the scores
+
+
+def test_validate_batch_semantics():
+    logits = torch.tensor([[0.0, 2.0, 2.0], [1.0, 0.0, 0.0]])
+    labels = torch.tensor([1, 2])
+    loss, correct = vgg_oracle.validate_batch(logits, labels)
+    assert correct == 1  # first max on ties -> class 1 for row 0
+    assert abs(float(loss) - float(torch.nn.functional.cross_entropy(logits, labels))) < 1e-7
+
+
+def test_goldens():
+    g = np.load(os.path.join(GOLD, "vgg_small.npz"))
+    torch.set_num_threads(8)
+    for name, c_in, seed in (("s", 3, 1), ("t", 20, 2)):
+        w = synth.synth_vgg16_weights(c_in=c_in, seed=seed)
+        if c_in != 3:
+            w["conv_w"][0] = vgg_oracle.copy_first_layer(w["conv_w"][0], c_in)
+        u = synth.hash_uniform(100 + seed, 77, 4 * c_in * 224 * 224).reshape(4, c_in, 224, 224)
+        x = torch.from_numpy(u * 4.0 - 2.0)[:2]
+        _, desc, logits = vgg_oracle.forward(x, w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"])
+        # different thread counts / vector ISAs may reorder torch's sums: 1e-4 leaves 10x headroom to 1e-3
+        assert np.abs(logits.numpy() - g["logits_" + name][:2]).max() < 1e-4
+        assert np.abs(desc.numpy() - g["desc_" + name][:2]).max() < 1e-4
+        # the fp32 oracle is itself within ~3e-5 of fp64 on these inputs
+        assert np.abs(g["logits_" + name][:1] - g["logits64_" + name]).max() < 1e-4

@@ -1,0 +1,135 @@
+"""End-to-end GPU parity: committed goldens, the full two-stream clip pipeline against the oracle,
+the reference-shaped Network.validate(), and size-independent properties at BASELINE.json's full
+batch (32 clips = 320 TV-L1 pairs)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-3
+
+
+def test_tvl1_against_committed_goldens():
+    from video_analytics_amd import flow as vflow
+    g = np.load(os.path.join(GOLD, "tvl1_64x48.npz"))
+    gray = torch.from_numpy(g["gray"]).cuda()
+    fixed = vflow.tvl1_flow(gray, epsilon=0.0, iters=30, warps=3)
+    assert np.array_equal(fixed.cpu().numpy(), g["flow_fixed"])
+    eps = vflow.tvl1_flow(gray, epsilon=0.01, iters=300)
+    assert np.array_equal(eps.cpu().numpy(), g["flow_eps"])
+    assert np.array_equal(vflow.flow_to_stack(fixed).cpu().numpy(), g["stack_fixed"])
+
+
+def test_vgg_against_committed_goldens():
+    from video_analytics_amd import pipeline, synth, vgg
+    g = np.load(os.path.join(GOLD, "vgg_small.npz"))
+    for name, c_in, seed in (("s", 3, 1), ("t", 20, 2)):
+        w = pipeline.build_stream_weights(c_in, seed, torch.device("cuda", 0))
+        m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256)
+        u = synth.hash_uniform(100 + seed, 77, 4 * c_in * 224 * 224).reshape(4, c_in, 224, 224)
+        x = torch.from_numpy(u * 4.0 - 2.0).cuda()
+        feat, desc, logits = m.forward(x, want_feat=True)
+        assert np.abs(logits.cpu().numpy() - g["logits_" + name]).max() < TOL
+        assert np.abs(desc.cpu().numpy() - g["desc_" + name]).max() < TOL
+        fs = feat.double().sum(dim=(1, 2, 3)).cpu().numpy()
+        assert np.abs(fs - g["feat_sum_" + name]).max() < 1e-3 * np.abs(g["feat_sum_" + name]).max()
+        # the split call surface of the reference: classify(features(x)) == forward(x)
+        d2, l2 = m.classify(m.features(x))
+        assert torch.equal(d2, desc) and torch.equal(l2, logits)
+        m.close()
+
+
+def test_two_stream_clip_pipeline_matches_oracle(oracle_tvl1):
+    from oracle import vgg_oracle
+    from video_analytics_amd import _ffi, pipeline, synth
+    from video_analytics_amd.parameters import NORM_MEANS_TF, NORM_STDS_TF
+    n = 2
+    rgb, gray, _ = synth.synth_clips(n, seed=12)
+    kw = dict(epsilon=0.0, iters=40, warps=2)
+    fl = oracle_tvl1.tvl1_flow(gray.numpy(), oracle_tvl1.default_params(**kw), nthreads=8)
+    st = torch.from_numpy(oracle_tvl1.flow_to_stack(fl).reshape(n, 20, 224, 224))
+    ws = synth.synth_vgg16_weights(c_in=3, seed=1)
+    wt = synth.synth_vgg16_weights(c_in=20, seed=2)
+    wt["conv_w"][0] = vgg_oracle.copy_first_layer(wt["conv_w"][0], 20)
+    _, ds, ls = vgg_oracle.forward(vgg_oracle.normalize_u8(rgb, NORM_MEANS_TF, NORM_STDS_TF), ws["conv_w"], ws["conv_b"], ws["fc_w"], ws["fc_b"])
+    _, dt, lt = vgg_oracle.forward(st, wt["conv_w"], wt["conv_b"], wt["fc_w"], wt["fc_b"])
+    pipe = pipeline.TwoStreamPipeline(device=0, tvl1_params=_ffi.default_tvl1_params(**kw))
+    assert torch.equal(pipe.flow_volume(gray.cuda()).cpu(), st)  # quantised flow volume: bit-exact
+    out = pipe.run_batch(rgb.cuda(), gray.cuda())
+    for got, ref in ((out["logits_s"], ls), (out["logits_t"], lt), (out["desc_s"], ds), (out["desc_t"], dt)):
+        assert float((got.cpu() - ref).abs().max()) < TOL
+    pipe.close()
+
+
+class _MemDataset(torch.utils.data.Dataset):
+    def __init__(self, x, labels):
+        self.x, self.labels = x, labels
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __getitem__(self, i):
+        return self.x[i], int(self.labels[i]), "v_Clip_g%02d_c%02d" % (i // 4 + 1, i % 4 + 1)
+
+
+def test_network_validate_matches_reference_semantics():
+    """SpatialNetwork/TemporalNetwork.validate(): accuracy, summed per-batch mean CE and per-video
+    descriptors equal the oracle's restatement of Sheet03/spatialModel.py:197-231."""
+    from oracle import vgg_oracle
+    from torch.utils.data import DataLoader
+    from video_analytics_amd import synth
+    from video_analytics_amd.spatialModel import SpatialNetwork
+    from video_analytics_amd.temporalModel import TemporalNetwork
+    for Net, c_in, seed, extra in ((SpatialNetwork, 3, 1, ()), (TemporalNetwork, 20, 2, (10,))):
+        w = synth.synth_vgg16_weights(c_in=c_in, seed=seed)
+        if c_in != 3:
+            w["conv_w"][0] = vgg_oracle.copy_first_layer(w["conv_w"][0], c_in)
+        u = synth.hash_uniform(50 + seed, 9, 5 * c_in * 224 * 224).reshape(5, c_in, 224, 224)
+        x = torch.from_numpy(u * 4.0 - 2.0)
+        _, desc_r, log_r = vgg_oracle.forward(x, w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"])
+        labels = log_r.argmax(1).clone()
+        labels[3] = (labels[3] + 1) % 101  # one wrong label
+        loader = DataLoader(_MemDataset(x, labels), batch_size=2, shuffle=False, num_workers=0)
+        loss_r, corr_r = 0.0, 0
+        for lo in range(0, 5, 2):
+            l, c = vgg_oracle.validate_batch(log_r[lo:lo + 2], labels[lo:lo + 2])
+            loss_r += float(l); corr_r += c
+        args = (101,) + extra + (1, 0.1, 0.9, 256, None, loader, [10, 20], None)
+        net = Net(*args, gpu=True, weights={k: [t.clone() for t in v] for k, v in w.items()})
+        acc, loss = net.validate()
+        assert acc == corr_r / 5 == 0.8
+        assert abs(float(loss) - loss_r) < 1e-3
+        assert len(net.testDict) == 5
+        d = net.testDict["v_Clip_g01_c03"][0].avg
+        assert float((d - desc_r[2]).abs().max()) < TOL
+        net.model.close()
+
+
+def test_full_batch_properties():
+    """BASELINE configs[1] size (32 clips, 320 pairs, full 5x5x300 schedule): results do not depend on
+    the temporal-blocking depth or on the batch a clip is in; static clips give exactly zero flow."""
+    from video_analytics_amd import _ffi, pipeline, synth
+    from video_analytics_amd import flow as vflow
+    rgb, gray, true_flow = synth.synth_clips(32, seed=0)
+    gray_d = gray.cuda()
+    gray_d[5] = gray_d[5, 0:1]  # clip 5: a static scene
+    fa = vflow.tvl1_flow(gray_d, epsilon=0.0, block_iters=5)
+    fb = vflow.tvl1_flow(gray_d, epsilon=0.0, block_iters=12)
+    assert torch.equal(fa, fb)
+    assert float(fa[50:60].abs().max()) == 0.0
+    alone = vflow.tvl1_flow(gray_d[7:8], epsilon=0.0)
+    assert torch.equal(alone, fa[70:80])
+    # the flow tracks the synthetic motion field away from the borders
+    c = slice(32, -32)
+    err = (fa[0:10, :, c, c].cpu() - true_flow[0][:, c, c]).abs().mean()
+    assert float(err) < 0.6, float(err)  # sanity only: mean |flow - synthetic field| in px
+    pipe = pipeline.TwoStreamPipeline(device=0, tvl1_params=_ffi.default_tvl1_params(epsilon=0.0))
+    stack = vflow.flow_to_stack(fa).view(32, 20, 224, 224)
+    out = pipe.run_batch(rgb.cuda(), flow_stack=stack)
+    one = pipe.run_batch(rgb[9:10].cuda(), flow_stack=stack[9:10])
+    assert torch.equal(one["logits_s"][0], out["logits_s"][9]) and torch.equal(one["logits_t"][0], out["logits_t"][9])
+    assert bool(torch.isfinite(out["logits_t"]).all())
+    pipe.close()

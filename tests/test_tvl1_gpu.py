@@ -39,8 +39,16 @@ def test_small_fixed_bit_exact(oracle_tvl1, block_iters):
 def test_shapes_fixed_bit_exact(oracle_tvl1, H, W):
     # 224x224: the benchmark size (all three tile configs through the pyramid);
     # 100x300: tiled in x with a halo; odd sizes: ragged rows/columns.
+    # 28 = 4*6 + 4: the last launch of every warp is shorter and uses its own tile grid
     gray = _frames(1, 3, H, W, seed=5)
-    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=24, warps=2)
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=28, warps=2)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
+@pytest.mark.parametrize("block_iters,iters", [(7, 23), (16, 40), (31, 70)])
+def test_block_depth_and_remainders_bit_exact(oracle_tvl1, block_iters, iters):
+    gray = _frames(2, 2, 224, 224, seed=13)
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=2, block_iters=block_iters)
     assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 

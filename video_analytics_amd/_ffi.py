@@ -15,7 +15,7 @@ VA_OK, VA_ERR_INVALID, VA_ERR_HIP, VA_ERR_WORKSPACE = 0, 1, 2, 3
 # every symbol include/va.h declares (tests check that the library exports exactly these)
 EXPORTS = [
     "va_version", "va_last_error", "va_ctx_create", "va_ctx_destroy",
-    "va_vgg16_create", "va_vgg16_destroy", "va_vgg16_workspace_bytes", "va_vgg16_forward",
+    "va_vgg16_create", "va_vgg16_destroy", "va_vgg16_workspace_bytes", "va_vgg16_forward", "va_vgg16_classify",
     "va_copy_first_layer", "va_validate_batch",
     "va_tvl1_default_params", "va_tvl1_pyramid_sizes", "va_tvl1_workspace_bytes", "va_tvl1_flow",
     "va_flow_to_stack", "va_tvl1_profile_enable", "va_tvl1_profile_read",
@@ -74,6 +74,8 @@ def lib():
     L.va_vgg16_workspace_bytes.restype = sz
     L.va_vgg16_forward.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]
     L.va_vgg16_forward.restype = ci
+    L.va_vgg16_classify.argtypes = [vp, vp, ci, vp, vp, vp, sz, vp]
+    L.va_vgg16_classify.restype = ci
     L.va_copy_first_layer.argtypes = [vp, vp, ci, ci, vp, vp]
     L.va_copy_first_layer.restype = ci
     L.va_validate_batch.argtypes = [vp, vp, vp, ci, ci, vp, vp]

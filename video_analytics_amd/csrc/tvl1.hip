@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const int y = y0 + c;
-        if (runok && y >= vy0 && y < vy1) {
+        if (runok && y >= vy0 && y < vy1 && y < h) {
             const size_t ro_ = (size_t)y * pitch;
             store_run<R>(sout + ro_, x0, pitch, u1[c]);
             store_run<R>(sout + a.plane + ro_, x0, pitch, u2[c]);
@@ -734,14 +734,19 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
             a.theta = p->theta;
             int launches = 0;
             for (int it = 0; it < p->iters;) {
+                // the tile grid depends on the halo depth: a shorter last launch gets its own grid
                 const int k = (p->iters - it) < tp.K ? (p->iters - it) : tp.K;
+                const TilePick tk = (k == tp.K) ? tp : pick_tiles(lw, lh, k);
+                a.ntx = tk.ntx;
+                a.nty = tk.nty;
+                a.HX = tk.HX;
                 a.cur = cur;
-                a.K = k;
+                a.K = tk.K;
                 a.it = it;
-                if (eps) launch_iter<true>(tp, a, P.NP, st);
-                else launch_iter<false>(tp, a, P.NP, st);
+                if (eps) launch_iter<true>(tk, a, P.NP, st);
+                else launch_iter<false>(tk, a, P.NP, st);
                 cur ^= 1;
-                it += k;
+                it += tk.K;
                 ++launches;
             }
             VA_LAUNCH_CHECK();

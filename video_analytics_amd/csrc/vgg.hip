@@ -539,6 +539,19 @@ WsPlan plan_ws(const va_vgg16* m, int B)
 
 }  // namespace
 
+// FC1..FC4 on an NHWC feature map f [B][7][7][512] (Sheet03/spatialModel.py:213-218).
+static int run_classifier(va_vgg16* m, const float* f, int B, void* desc, void* logits, float* slab, float* const* fcbuf,
+                          hipStream_t st)
+{
+    if (int rc = launch_fc(f, m->fcw[0], m->fcb[0], fcbuf[0], slab, B, 4096, 512 * 49, true, st)) return rc;
+    if (int rc = launch_fc(fcbuf[0], m->fcw[1], m->fcb[1], fcbuf[1], slab, B, 4096, 4096, true, st)) return rc;
+    float* d = desc ? (float*)desc : fcbuf[0];
+    if (int rc = launch_fc(fcbuf[1], m->fcw[2], m->fcb[2], d, slab, B, m->desc_dim, 4096, true, st)) return rc;
+    if (logits)
+        if (int rc = launch_fc(d, m->fcw[3], m->fcb[3], (float*)logits, slab, B, m->n_classes, m->desc_dim, false, st)) return rc;
+    return VA_OK;
+}
+
 extern "C" int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_dim, int dtype,
                                const void* const* conv_w, const void* const* conv_b, const void* const* fc_w,
                                const void* const* fc_b, const float* in_mean, const float* in_std, void* stream,
@@ -674,14 +687,31 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
         k_nhwc_to_nchw<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(f, (float*)feat, B, 512, 49);
         VA_LAUNCH_CHECK();
     }
-    if (desc || logits) {
-        if (int rc = launch_fc(f, m->fcw[0], m->fcb[0], fcbuf[0], slab, B, 4096, 512 * 49, true, st)) return rc;
-        if (int rc = launch_fc(fcbuf[0], m->fcw[1], m->fcb[1], fcbuf[1], slab, B, 4096, 4096, true, st)) return rc;
-        float* d = desc ? (float*)desc : fcbuf[0];
-        if (int rc = launch_fc(fcbuf[1], m->fcw[2], m->fcb[2], d, slab, B, m->desc_dim, 4096, true, st)) return rc;
-        if (logits)
-            if (int rc = launch_fc(d, m->fcw[3], m->fcb[3], (float*)logits, slab, B, m->n_classes, m->desc_dim, false, st)) return rc;
+    if (desc || logits) return run_classifier(m, f, B, desc, logits, slab, fcbuf, st);
+    return VA_OK;
+}
+
+extern "C" int va_vgg16_classify(va_vgg16* m, const void* feat, int batch, void* desc, void* logits, void* workspace,
+                                 size_t workspace_bytes, void* stream)
+{
+    VA_CHECK_ARG(m != nullptr, "va_vgg16_classify: model is NULL");
+    VA_CHECK_ARG(feat != nullptr && workspace != nullptr, "va_vgg16_classify: NULL input/workspace");
+    VA_CHECK_ARG(batch >= 1 && batch <= 4096, "va_vgg16_classify: batch %d out of range [1,4096]", batch);
+    VA_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "va_vgg16_classify: workspace must be 256-byte aligned");
+    const WsPlan wp = plan_ws(m, batch);
+    if (workspace_bytes < wp.total) {
+        va_set_error("va_vgg16_classify: workspace too small (%zu < %zu bytes)", workspace_bytes, wp.total);
+        return VA_ERR_WORKSPACE;
     }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* nhwc = (float*)(ws + wp.off_act[0]);
+    float* slab = (float*)(ws + wp.off_slab);
+    float* fcbuf[2] = {(float*)(ws + wp.off_fc[0]), (float*)(ws + wp.off_fc[1])};
+    const size_t n = (size_t)batch * 49;
+    k_nchw_to_nhwc_pad<float><<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const float*)feat, nhwc, batch, 512, 49, 512, nullptr, nullptr);
+    VA_LAUNCH_CHECK();
+    if (desc || logits) return run_classifier(m, nhwc, batch, desc, logits, slab, fcbuf, st);
     return VA_OK;
 }
 

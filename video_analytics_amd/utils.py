@@ -1,0 +1,231 @@
+"""Host-side helpers of the two-stream path: the reference's ``Sheet03/utils.py`` surface.
+
+Pure-Python string/indexing logic is bit-exact with the reference lines cited per function.
+The image transforms restate the torchvision ~0.2 classes the reference composes
+(``getTransforms``, Sheet03/utils.py:137-151) on numpy/torch, because torchvision is not part of this
+stack; they draw from Python's global ``random`` module in the same order as that torchvision
+generation (crop top, crop left, flip).  Training bookkeeping (``makeCheckpoint``,
+``savePerformance``) and video decoding (``extractEveryNthFrame``, ``convertVideosToFrames``; need
+``cv2``) are outside the hot path and not provided.
+"""
+from __future__ import division
+
+import csv
+import os
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from .parameters import *  # noqa: F401,F403  (the reference star-imports its config the same way)
+from .parameters import (COLOR_JITTERS, CROP_SIZE_TF, HORIZONTAL_FLIP_TF, NORM_MEANS_TF, NORM_STDS_TF,
+                         NWORKERS_LOADER, SHUFFLE_LOADER, TEMPORAL_BATCH_SIZE)
+
+
+def checkAndMakeDirectories(*args):
+    """Create missing directories; item i is True if directory i already existed
+    (Sheet03/utils.py:14-26)."""
+    exists = [True] * len(args)
+    for i, arg in enumerate(args):
+        if not os.path.exists(arg):
+            exists[i] = False
+            os.makedirs(arg)
+    return exists
+
+
+def videoInfo(line, mode):
+    """Parse one video-list line (Sheet03/utils.py:73-91).
+
+    Returns (videoLoc, videoName, actionLabel or None, actionCategory, ngroup, nclip).
+    train lines are ``"Cat/v_Cat_gNN_cNN.avi K"`` (exactly one space), test lines have no label.
+    Raises ValueError exactly where the reference's tuple unpacking does (wrong number of
+    ``" "``, ``"/"`` or ``"_"`` separated parts).
+    """
+    actionLabel = None
+    if mode == "train":
+        videoLoc, actionLabel = line.split(" ")
+        actionLabel = actionLabel.strip()
+    else:
+        videoLoc = line
+    videoLoc = videoLoc.strip()
+    actionCategory, videoName = videoLoc.split("/")
+    actionCategory = actionCategory.strip()
+    videoName = videoName[:videoName.rfind(".")]
+    _, _, ngroup, nclip = videoName.split("_")
+    return videoLoc, videoName, actionLabel, actionCategory, ngroup, nclip
+
+
+def spatialFrameIndex(nFrames, r=None):
+    """Index of the frame ``SpatialDataset.__getitem__`` opens: ``random.randint(0, nFrames-1)``,
+    both ends inclusive (Sheet03/spatialModel.py:74-77).  ``r`` overrides the draw (tests)."""
+    if nFrames < 1:
+        raise ValueError("empty range for randrange() (0, %d, %d)" % (nFrames, nFrames))
+    return random.randint(0, nFrames - 1) if r is None else r
+
+
+def temporalFlowIndices(nFiles, flowSampleSize, r=None):
+    """Start index and the 2L interleaved (prefix, index) pairs ``TemporalDataset.__getitem__`` opens
+    (Sheet03/temporalModel.py:78-83).
+
+    ``nFlows = nFiles / 2`` is a TRUE division in the reference (``from __future__ import division``)
+    and Python 2's ``randint`` rejects a non-integral float bound, so an odd file count raises
+    ValueError; the start lies in [1, nFlows - L] (the last flow index nFlows is never read).
+    Order: x_s, y_s, x_{s+1}, y_{s+1}, ... (exactly 2L entries).
+    """
+    nFlows = nFiles / 2
+    if nFlows != int(nFlows):
+        raise ValueError("non-integer stop for randrange()")
+    nFlows = int(nFlows)
+    hi = nFlows - flowSampleSize
+    if hi < 1:
+        raise ValueError("empty range for randrange() (1, %d, %d)" % (hi + 1, hi))
+    start = random.randint(1, hi) if r is None else r
+    order = []
+    for idx in range(start, start + flowSampleSize):
+        order.append(("x", idx))
+        order.append(("y", idx))
+    return start, order
+
+
+def flowFileName(prefix, idx, extn=".jpg"):
+    """``flow_x_0007.jpg`` naming: prefix + 4-digit zero-padded 1-based index (Sheet03/temporalModel.py:80-81)."""
+    return prefix + str(idx).zfill(4) + extn
+
+
+# ----------------------------------------------------------------------------- transforms ------
+
+class RandomCrop(object):
+    """``transforms.RandomCrop(224)``: top = randint(0, h-th), left = randint(0, w-tw)."""
+
+    def __init__(self, size):
+        self.size = (int(size), int(size))
+
+    def __call__(self, img):
+        h, w = img.shape[0], img.shape[1]
+        th, tw = self.size
+        if w == tw and h == th:
+            return img
+        if h < th or w < tw:
+            raise ValueError("Required crop size %s is larger than input image size %s" % ((th, tw), (h, w)))
+        i = random.randint(0, h - th)
+        j = random.randint(0, w - tw)
+        return img[i:i + th, j:j + tw]
+
+
+class RandomHorizontalFlip(object):
+    def __init__(self, p=0.5):
+        self.p = p
+
+    def __call__(self, img):
+        if random.random() < self.p:
+            return img[:, ::-1]
+        return img
+
+
+class ColorJitter(object):
+    """``ColorJitter(0,0,0,0)`` (Sheet03/parameters.py:21) is the identity and draws no random numbers."""
+
+    def __init__(self, brightness=0, contrast=0, saturation=0, hue=0):
+        if brightness or contrast or saturation or hue:
+            raise NotImplementedError("only the reference's ColorJitter(0,0,0,0) (identity) is supported")
+
+    def __call__(self, img):
+        return img
+
+
+class ToTensor(object):
+    """u8 HWC (or HW) -> float32 CHW / 255."""
+
+    def __call__(self, img):
+        a = np.ascontiguousarray(img)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        t = torch.from_numpy(a.transpose(2, 0, 1).copy())
+        return t.to(torch.float32).div(255)
+
+
+class Normalize(object):
+    """Per-channel (t - mean)/std over ``zip(tensor, mean, std)``: a 1-channel flow image therefore
+    uses only the FIRST mean/std pair (0.485 / 0.229) -- SURVEY.md a5, appendix quirk 3."""
+
+    def __init__(self, mean, std):
+        self.mean, self.std = list(mean), list(std)
+
+    def __call__(self, t):
+        out = t.clone()
+        for c, (m, s) in enumerate(zip(self.mean, self.std)):
+            if c >= out.shape[0]:
+                break
+            out[c] = (out[c] - m) / s
+        return out
+
+
+class Compose(object):
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, img):
+        img = np.asarray(img)
+        for t in self.transforms:
+            img = t(img)
+        return img
+
+
+def getTransforms(cropSize=CROP_SIZE_TF, hortizontalFlip=HORIZONTAL_FLIP_TF, normMeans=NORM_MEANS_TF,
+                  normStds=NORM_STDS_TF, jitter=COLOR_JITTERS):
+    """Sheet03/utils.py:137-151.  The crop is the literal 224 of the reference whatever ``cropSize``
+    says (``:143``); the same random transforms are used at test time (Sheet03/spatialModel.py:293-294)."""
+    imgTrans = []
+    if cropSize:
+        imgTrans.append(RandomCrop(224))
+    if hortizontalFlip:
+        imgTrans.append(RandomHorizontalFlip())
+    if jitter:
+        imgTrans.append(ColorJitter(*jitter))
+    imgTrans.append(ToTensor())
+    if normMeans and normStds:
+        imgTrans.append(Normalize(mean=normMeans, std=normStds))
+    return Compose(imgTrans)
+
+
+def getDataLoader(dataset, batchSize=TEMPORAL_BATCH_SIZE, nWorkers=NWORKERS_LOADER, shuffle=SHUFFLE_LOADER):
+    """Sheet03/utils.py:125-133: default collate, last batch partial, shuffle on (also for test)."""
+    return DataLoader(dataset=dataset, batch_size=batchSize, shuffle=shuffle, num_workers=nWorkers)
+
+
+class AverageMeter(object):
+    """Running mean (Sheet03/utils.py:154-171)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = 0
+        self.avg = 0
+        self.sum = 0
+        self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def saveVideoDescriptors(videoDescDict, csvLoc, gpu=False):
+    """One CSV row per video: ``name,label,`` then the descriptor as float64 reprs
+    (Sheet03/utils.py:174-195; the width is VIDEO_DESCRIPTOR_DIM = 256, not the docstring's 4096)."""
+    try:
+        os.remove(csvLoc)
+    except OSError:
+        pass
+    with open(csvLoc, "a") as csvFile:
+        writer = csv.writer(csvFile, delimiter=",")
+        for videoName in videoDescDict.keys():
+            label = videoDescDict[videoName][1]
+            videoLabel = label.cpu().numpy() if isinstance(label, torch.Tensor) else np.asarray(label)
+            csvFile.write(videoName + "," + str(videoLabel) + ",")
+            videoDesc = videoDescDict[videoName][0].avg
+            videoDesc = videoDesc.detach().cpu().numpy().astype(float)
+            writer.writerow(videoDesc)

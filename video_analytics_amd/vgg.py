@@ -119,6 +119,39 @@ class Vgg16Stream(object):
         return feat, desc, logits
 
 
+    def features(self, x):
+        """``self.features(ip)`` of the reference (Sheet03/spatialModel.py:212): [B,C,224,224] -> [B,512,7,7]."""
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise ValueError("Vgg16Stream.features: x must be a CUDA tensor")
+        if x.dim() != 4 or tuple(x.shape[1:]) != (self.c_in, 224, 224) or x.dtype not in (torch.float32, torch.uint8):
+            raise ValueError("Vgg16Stream.features: x must be float32/uint8 [B,%d,224,224]" % self.c_in)
+        x = x.contiguous()
+        B = x.shape[0]
+        L = _ffi.lib()
+        ws = _workspace(L.va_vgg16_workspace_bytes(self._h, B), x.device)
+        feat = torch.empty((B, 512, 7, 7), dtype=torch.float32, device=x.device)
+        _ffi.check(L.va_vgg16_forward(self._h, _ffi.ptr(x), int(x.dtype == torch.uint8), B, _ffi.ptr(feat), None, None,
+                                      _ffi.ptr(ws), ws.numel(), _ffi.stream_ptr()))
+        return feat
+
+    def classify(self, feat):
+        """The classifierList traversal (Sheet03/spatialModel.py:213-218): feat [B,512,7,7] ->
+        (featureVectors [B,D] = output of module 8, logits [B,nClasses] = output of module 9)."""
+        if not isinstance(feat, torch.Tensor) or not feat.is_cuda or feat.dtype != torch.float32:
+            raise ValueError("Vgg16Stream.classify: feat must be a CUDA float32 tensor")
+        if feat.dim() != 4 or tuple(feat.shape[1:]) != (512, 7, 7):
+            raise ValueError("Vgg16Stream.classify: feat must be [B,512,7,7]")
+        feat = feat.contiguous()
+        B = feat.shape[0]
+        L = _ffi.lib()
+        ws = _workspace(L.va_vgg16_workspace_bytes(self._h, B), feat.device)
+        desc = torch.empty((B, self.desc_dim), dtype=torch.float32, device=feat.device)
+        logits = torch.empty((B, self.n_classes), dtype=torch.float32, device=feat.device)
+        _ffi.check(L.va_vgg16_classify(self._h, _ffi.ptr(feat), B, _ffi.ptr(desc), _ffi.ptr(logits), _ffi.ptr(ws),
+                                       ws.numel(), _ffi.stream_ptr()))
+        return desc, logits
+
+
 def _ffi_conv_cout(i):
     return (64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512)[i]
 
