@@ -31,6 +31,28 @@ BYTES_PER_PX_WARP = 44.0
 BATCH = 32
 
 
+def pmc_traffic_per_launch(block_iters):
+    """HBM bytes per k_iter_tile launch from the committed rocprofv3 PMC passes (profiles/rNN/
+    pmc_hbm_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command;
+    FETCH_SIZE doubled per the gfx950 rule of MI355X_MICROARCH.md, verified on this kernel's known
+    load count in profiles/README.md).  PMC cannot be collected inside a normal run: this reports the
+    profiled figure for the same configuration, or None if no profile matches."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm_summary.json")))
+    if not cands:
+        return None
+    try:
+        d = json.load(open(cands[-1]))
+        if int(d.get("block_iters", 12)) != (block_iters or 12):
+            return None
+        f = sum(v["sum_KB"] for k, v in d["FETCH_SIZE"].items() if k.startswith("k_iter"))
+        w = sum(v["sum_KB"] for k, v in d["WRITE_SIZE"].items() if k.startswith("k_iter"))
+        n = sum(v["launches"] for k, v in d["FETCH_SIZE"].items() if k.startswith("k_iter"))
+        return (2.0 * f + w) * 1024.0 / n
+    except Exception:
+        return None
+
+
 def cpu_baseline(n_clips, tv_kw):
     """CPU oracle on `n_clips` clips of the same workload: the checker, timed as a reported baseline."""
     import torch
@@ -137,7 +159,7 @@ def main():
             alg_bytes = BYTES_PER_PX_ITER * prof["px_iters"]
             ach = alg_bytes / (prof["ms"] * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel="k_iter_tile (TV-L1 inner iterations)", achieved=ach, peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                        unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=pmc_traffic_per_launch(args.block_iters),
                         launches=int(prof["launches"]), avg_launch_us=prof["ms"] * 1e3 / prof["launches"],
                         alg_bytes_per_launch=alg_bytes / prof["launches"], kernel_ms_per_step=prof["ms"] / max(K, 1))
         cpu = None
