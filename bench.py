@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--block-iters", type=int, default=0, help="TV-L1 temporal blocking depth (0 = library default)")
+    ap.add_argument("--tvl1-math", choices=["exact", "fast"], default="exact",
+                    help="exact: bit-identical to the CPU oracle; fast: 1-ulp hardware sqrt/rcp (tolerance-tested)")
     ap.add_argument("--cpu-clips", type=int, default=2, help="clips in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-flow", action="store_true", help="CNN only on precomputed flow volumes (not the headline metric)")
     args = ap.parse_args()
@@ -113,7 +115,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     tv_kw = dict(epsilon=0.0, iters=300, warps=5, nscales=5)
-    params = _ffi.default_tvl1_params(block_iters=args.block_iters, **tv_kw)
+    params = _ffi.default_tvl1_params(block_iters=args.block_iters, fast_math=int(args.tvl1_math == "fast"), **tv_kw)
     pipe = pipeline.TwoStreamPipeline(device=local_rank, tvl1_params=params)
     # distinct clips per rank: clip index = rank*BATCH + i
     rgb, gray, _ = synth.synth_clips(BATCH, seed=0, first_clip=rank * BATCH)
@@ -172,7 +174,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "two-stream 224x224, 10-frame TV-L1 flow stack (5 scales x 5 warps x 300 its, fixed), "
                                    "VGG-16 spatial+temporal, batch=32 per GPU" + (" [CNN only: --no-flow]" if args.no_flow else ""),
-                       "global_batch": world * BATCH, "block_iters": args.block_iters, "parallelism": "clips sharded x%d" % world,
+                       "global_batch": world * BATCH, "block_iters": args.block_iters, "tvl1_math": args.tvl1_math, "parallelism": "clips sharded x%d" % world,
                        "finite": finite},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -116,6 +116,11 @@ typedef struct va_tvl1_params {
     int block_iters;  /* inner iterations fused per launch (register-resident temporal
                          blocking); 0 = library default.  Results do not depend on it.
                          Forced to 1 when epsilon > 0. */
+    int fast_math;    /* 0 (default): the exact arithmetic contract of DESIGN.md (correctly rounded
+                         sqrt and division): results bit-identical to the CPU oracle.
+                         1: the two special functions of the dual update use the 1-ulp hardware
+                         v_sqrt_f32 / v_rcp_f32 (1.6x faster inner iterations; flow within ~1e-4 px
+                         of the exact mode, tested with a 1e-3 px tolerance). */
 } va_tvl1_params;
 
 void va_tvl1_default_params(va_tvl1_params* p);
@@ -142,6 +147,13 @@ int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, int n_seq, 
  */
 int va_flow_to_stack(va_ctx* ctx, const void* flow, int n_pairs, int w, int h,
                      float bound, float mean, float stdv, void* stack, void* stream);
+
+/*
+ * Self-test of the arithmetic contract: compares the kernel's packed correctly-rounded sqrt and
+ * reciprocal sequences with IEEE sqrtf / division on EVERY float in [lo, hi] (within [2^-100, 1e30];
+ * the reciprocal on the part >= 1).  mismatches: DEVICE u64[2] = {sqrt, reciprocal} counts.
+ */
+int va_selftest_exact_math(va_ctx* ctx, float lo, float hi, unsigned long long* mismatches, void* stream);
 
 /*
  * Measurement hooks (bench.py): when enabled, va_tvl1_flow brackets every run of

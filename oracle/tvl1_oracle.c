@@ -52,8 +52,9 @@
  *               written as a clamp: the three IPOL cases coincide with it)
  *         v1  = fmaf(fi,I1wx,u1);  v2 = fmaf(fi,I1wy,u2);
  *         u1' = fmaf(theta, div(p11,p12), v1);  (same for u2)
- *         g1  = sqrtf(fmaf(u1y,u1y, u1x*u1x)); r1 = 1/fmaf(taut,g1,1);
- *         p11 = fmaf(taut,u1x,p11)*r1; p12 = fmaf(taut,u1y,p12)*r1; (same p2*)
+ *         d1  = fmaf(taut, sqrtf(fmaf(u1y,u1y, u1x*u1x)), 1); d2 likewise from u2;
+ *         rinv = 1/(d1*d2); r1 = d2*rinv; r2 = d1*rinv;   (1/d1 and 1/d2 from ONE division)
+ *         p11 = fmaf(taut,u1x,p11)*r1; p12 = fmaf(taut,u1y,p12)*r1; p21, p22 with r2
  *       with l_t = lambda*theta, taut = tau/theta, backward-difference
  *       divergence and forward-difference gradient with the IPOL boundary
  *       rules.
@@ -255,16 +256,17 @@ long ora_tvl1_level(const float* I0, const float* I1, const float* I1x, const fl
             memcpy(u2, n2, n * sizeof(float));
             for (y = 0; y < h; y++)
                 for (x = 0; x < w; x++) {
-                    float u1x, u1y, u2x, u2y, g1, g2, r1, r2;
+                    float u1x, u1y, u2x, u2y, d1, d2, rinv, r1, r2;
                     i = (size_t)y * w + x;
                     u1x = x < w - 1 ? u1[i + 1] - u1[i] : 0.0f;
                     u1y = y < h - 1 ? u1[i + w] - u1[i] : 0.0f;
                     u2x = x < w - 1 ? u2[i + 1] - u2[i] : 0.0f;
                     u2y = y < h - 1 ? u2[i + w] - u2[i] : 0.0f;
-                    g1 = sqrtf(fmaf(u1y, u1y, u1x * u1x));
-                    g2 = sqrtf(fmaf(u2y, u2y, u2x * u2x));
-                    r1 = 1.0f / fmaf(taut, g1, 1.0f);
-                    r2 = 1.0f / fmaf(taut, g2, 1.0f);
+                    d1 = fmaf(taut, sqrtf(fmaf(u1y, u1y, u1x * u1x)), 1.0f);
+                    d2 = fmaf(taut, sqrtf(fmaf(u2y, u2y, u2x * u2x)), 1.0f);
+                    rinv = 1.0f / (d1 * d2); /* one division per pixel: 1/d1 = d2/(d1 d2) */
+                    r1 = d2 * rinv;
+                    r2 = d1 * rinv;
                     p11[i] = fmaf(taut, u1x, p11[i]) * r1;
                     p12[i] = fmaf(taut, u1y, p12[i]) * r1;
                     p21[i] = fmaf(taut, u2x, p21[i]) * r2;

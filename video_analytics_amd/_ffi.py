@@ -18,7 +18,7 @@ EXPORTS = [
     "va_vgg16_create", "va_vgg16_destroy", "va_vgg16_workspace_bytes", "va_vgg16_forward", "va_vgg16_classify",
     "va_copy_first_layer", "va_validate_batch",
     "va_tvl1_default_params", "va_tvl1_pyramid_sizes", "va_tvl1_workspace_bytes", "va_tvl1_flow",
-    "va_flow_to_stack", "va_tvl1_profile_enable", "va_tvl1_profile_read",
+    "va_flow_to_stack", "va_selftest_exact_math", "va_tvl1_profile_enable", "va_tvl1_profile_read",
 ]
 
 
@@ -34,6 +34,7 @@ class Tvl1Params(ctypes.Structure):
         ("iters", ctypes.c_int),
         ("scale_step", ctypes.c_float),
         ("block_iters", ctypes.c_int),
+        ("fast_math", ctypes.c_int),
     ]
 
 
@@ -90,6 +91,8 @@ def lib():
     L.va_tvl1_flow.restype = ci
     L.va_flow_to_stack.argtypes = [vp, vp, ci, ci, ci, cf, cf, cf, vp, vp]
     L.va_flow_to_stack.restype = ci
+    L.va_selftest_exact_math.argtypes = [vp, cf, cf, vp, vp]
+    L.va_selftest_exact_math.restype = ci
     L.va_tvl1_profile_enable.argtypes = [vp, ci]
     L.va_tvl1_profile_enable.restype = ci
     L.va_tvl1_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ci]

@@ -241,49 +241,87 @@ __device__ __forceinline__ float dpp_from_right(float v)  // lane i <- lane i+1,
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
-template <int R>
-__device__ __forceinline__ void load_run(const float* __restrict__ row, int x0, int pitch, bool rowok, float (&v)[R])
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f32
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+
+// Correctly rounded square root and reciprocal from the 1-ulp hardware seeds with packed FMAs only
+// (Markstein-style: no denormal scaling, no special-case selects).  Both are bit-identical to the
+// IEEE sqrtf() / 1.0f/x of the arithmetic contract on their whole domain: va_selftest_exact_math()
+// compares them EXHAUSTIVELY (every float in [2^-100, 1e30] resp. [1, 1e30]) against the compiler's
+// correctly rounded expansions; tests/test_tvl1_gpu.py runs that check.
+constexpr float kSqrtReg = 7.888609052210118e-31f;  // 2^-100
+__device__ __forceinline__ f2 sqrt_exact_pk(f2 s)  // s in [2^-100, 1e30]
+{
+    const f2 y = f2{__builtin_amdgcn_rsqf(s.x), __builtin_amdgcn_rsqf(s.y)};
+    const f2 g0 = s * y, h0 = y * 0.5f;
+    const f2 r = pk_fma(-h0, g0, splat(0.5f));
+    const f2 g1 = pk_fma(g0, r, g0), h1 = pk_fma(h0, r, h0);
+    const f2 d = pk_fma(-g1, g1, s);
+    return pk_fma(d, h1, g1);
+}
+__device__ __forceinline__ f2 rcp_exact_pk(f2 d)  // d in [1, 1e30]
+{
+    const f2 r = f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const f2 e0 = pk_fma(-d, r, splat(1.0f));
+    const f2 r1 = pk_fma(e0, r, r);
+    const f2 e1 = pk_fma(-d, r1, splat(1.0f));
+    return pk_fma(e1, r1, r1);
+}
+
+__global__ void k_selftest_exact_math(unsigned lo, unsigned long long n, unsigned long long* bad)
+{
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long b0 = 0, b1 = 0;
+    for (; i < n; i += stride) {
+        const float x = __uint_as_float(lo + (unsigned)i);
+        const f2 v = f2{x, x};
+        b0 += __float_as_uint(sqrt_exact_pk(v).y) != __float_as_uint(sqrtf(x));
+        if (x >= 1.0f) b1 += __float_as_uint(rcp_exact_pk(v).x) != __float_as_uint(1.0f / x);
+    }
+    if (b0) atomicAdd(&bad[0], b0);
+    if (b1) atomicAdd(&bad[1], b1);
+}
+
+// RP float2 per row: RP == 1 -> one 8-byte access, RP == 2 -> one 16-byte access.
+template <int RP>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, int x0, int pitch, bool rowok, f2 (&v)[RP])
 {
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = 0.0f;
-    if (!rowok) return;
-    if constexpr (R == 4) {
-        if (x0 < pitch) {
-            const float4 t = *reinterpret_cast<const float4*>(row + x0);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-        }
-    } else if constexpr (R == 2) {
-        if (x0 < pitch) {
-            const float2 t = *reinterpret_cast<const float2*>(row + x0);
-            v[0] = t.x; v[1] = t.y;
-        }
+    for (int j = 0; j < RP; ++j) v[j] = f2{0.0f, 0.0f};
+    if (!rowok || x0 >= pitch) return;
+    if constexpr (RP == 2) {
+        const float4 t = *reinterpret_cast<const float4*>(row + x0);
+        v[0] = f2{t.x, t.y};
+        v[1] = f2{t.z, t.w};
     } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (x0 + r < pitch) v[r] = row[x0 + r];
+        const float2 t = *reinterpret_cast<const float2*>(row + x0);
+        v[0] = f2{t.x, t.y};
     }
 }
 
-template <int R>
-__device__ __forceinline__ void store_run(float* __restrict__ row, int x0, int pitch, const float (&v)[R])
+template <int RP>
+__device__ __forceinline__ void store_row(float* __restrict__ row, int x0, int pitch, const f2 (&v)[RP])
 {
-    if constexpr (R == 4) {
-        if (x0 < pitch) *reinterpret_cast<float4*>(row + x0) = make_float4(v[0], v[1], v[2], v[3]);
-    } else if constexpr (R == 2) {
-        if (x0 < pitch) *reinterpret_cast<float2*>(row + x0) = make_float2(v[0], v[1]);
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (x0 + r < pitch) row[x0 + r] = v[r];
-    }
+    if (x0 >= pitch) return;
+    if constexpr (RP == 2) *reinterpret_cast<float4*>(row + x0) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+    else *reinterpret_cast<float2*>(row + x0) = make_float2(v[0].x, v[0].y);
 }
 
-// S6 (+S7 when EPS).  Tile = (64*R) x (NW*C) pixels, thread patch = R x C, K iterations per launch.
-template <int R, int C, int NW, bool EPS>
+// S6 (+S7 when EPS).  Tile = (128*RP) x (NW*C) pixels; a thread keeps C rows of 2*RP pixels of all ten
+// fields in registers as float2 pairs, so that the bulk of the arithmetic issues as v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32 (two pixels per VALU instruction: a wave64 VALU instruction occupies
+// its SIMD for 4 cycles on gfx950 whether it is packed or not -- measured, profiles/README.md).
+//
+// LX = lanes of a wave along x (64, or 32: the wave is folded into two row groups so that a 128-pixel
+// wide tile still uses 16-byte accesses); NG = NW*64/LX row groups of C rows each.
+template <int RP, int C, int NW, int LX, bool EPS, bool FAST>
 __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
 {
-    constexpr int TW = 64 * R, TH = NW * C;
-    __shared__ float sP12[NW][TW], sP22[NW][TW], sU1[NW][TW], sU2[NW][TW];
+    constexpr int R = 2 * RP, TW = LX * R, NG = NW * (64 / LX), TH = NG * C;
+    __shared__ __attribute__((aligned(16))) float sP12[NG][TW], sP22[NG][TW], sU1[NG][TW], sU2[NG][TW];
     __shared__ unsigned long long sErr;
 
     const int pair = blockIdx.y;
@@ -296,156 +334,189 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
         if (blockIdx.x == 0 && threadIdx.x == 0) a.sel[pair] = inbuf ^ 1;
         if (threadIdx.x == 0) sErr = 0ull;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = (threadIdx.x & 63) & (LX - 1);                       // position along x
+    const int wave = (threadIdx.x >> 6) * (64 / LX) + (threadIdx.x & 63) / LX;  // row group
     const int tx = blockIdx.x % a.ntx, ty = blockIdx.x / a.ntx;
     const int w = a.w, h = a.h, pitch = a.pitch, K = a.K;
     const int ox = tx * (TW - 2 * a.HX), oy = ty * (TH - 2 * K);
     const int vx0 = ox + (tx > 0 ? a.HX : 0), vx1 = (tx == a.ntx - 1) ? w : ox + TW - a.HX;
     const int vy0 = oy + (ty > 0 ? K : 0), vy1 = (ty == a.nty - 1) ? h : oy + TH - K;
     const int x0 = ox + lane * R, y0 = oy + wave * C;
+    // folded waves: lane LX's DPP "left neighbour" is the last lane of the other row group
+    const float lfix = (LX == 64 || lane > 0) ? 1.0f : 0.0f;
 
     const float* __restrict__ ro = a.ro + (size_t)pair * kNF_RO * a.plane;
     const float* __restrict__ sin = (inbuf ? a.stB : a.stA) + (size_t)pair * kNF_STATE * a.plane;
     float* __restrict__ sout = (inbuf ? a.outA : a.outB) + (size_t)pair * kNF_STATE * a.plane;
 
-    float u1[C][R], u2[C][R], p11[C][R], p12[C][R], p21[C][R], p22[C][R];
-    float wx[C][R], wy[C][R], rc[C][R], ig[C][R];
-#pragma unroll
+    f2 u1[C][RP], u2[C][RP], p11[C][RP], p12[C][RP], p21[C][RP], p22[C][RP];
+    f2 wx[C][RP], wy[C][RP], rc[C][RP], ig[C][RP];
+#pragma clang loop unroll(full)
     for (int c = 0; c < C; ++c) {
         const int y = y0 + c;
         const bool rowok = y < h;
         const size_t ro_ = (size_t)y * pitch;
-        load_run<R>(sin + ro_, x0, pitch, rowok, u1[c]);
-        load_run<R>(sin + a.plane + ro_, x0, pitch, rowok, u2[c]);
-        load_run<R>(sin + 2 * a.plane + ro_, x0, pitch, rowok, p11[c]);
-        load_run<R>(sin + 3 * a.plane + ro_, x0, pitch, rowok, p12[c]);
-        load_run<R>(sin + 4 * a.plane + ro_, x0, pitch, rowok, p21[c]);
-        load_run<R>(sin + 5 * a.plane + ro_, x0, pitch, rowok, p22[c]);
-        load_run<R>(ro + ro_, x0, pitch, rowok, wx[c]);
-        load_run<R>(ro + a.plane + ro_, x0, pitch, rowok, wy[c]);
-        load_run<R>(ro + 2 * a.plane + ro_, x0, pitch, rowok, rc[c]);
-        load_run<R>(ro + 3 * a.plane + ro_, x0, pitch, rowok, ig[c]);
+        load_row<RP>(sin + ro_, x0, pitch, rowok, u1[c]);
+        load_row<RP>(sin + a.plane + ro_, x0, pitch, rowok, u2[c]);
+        load_row<RP>(sin + 2 * a.plane + ro_, x0, pitch, rowok, p11[c]);
+        load_row<RP>(sin + 3 * a.plane + ro_, x0, pitch, rowok, p12[c]);
+        load_row<RP>(sin + 4 * a.plane + ro_, x0, pitch, rowok, p21[c]);
+        load_row<RP>(sin + 5 * a.plane + ro_, x0, pitch, rowok, p22[c]);
+        load_row<RP>(ro + ro_, x0, pitch, rowok, wx[c]);
+        load_row<RP>(ro + a.plane + ro_, x0, pitch, rowok, wy[c]);
+        load_row<RP>(ro + 2 * a.plane + ro_, x0, pitch, rowok, rc[c]);
+        load_row<RP>(ro + 3 * a.plane + ro_, x0, pitch, rowok, ig[c]);
     }
 
-    const float l_t = a.l_t, taut = a.taut, theta = a.theta;
+    // Forward-difference border rule as 0/1 multipliers (x < w-1, y < h-1): exact (d*1 = d, d*0 = 0).
+    f2 mx[RP];
+    float my[C];
+#pragma clang loop unroll(full)
+    for (int j = 0; j < RP; ++j) mx[j] = f2{x0 + 2 * j < w - 1 ? 1.0f : 0.0f, x0 + 2 * j + 1 < w - 1 ? 1.0f : 0.0f};
+#pragma clang loop unroll(full)
+    for (int c = 0; c < C; ++c) my[c] = y0 + c < h - 1 ? 1.0f : 0.0f;
+
+    const float l_t = a.l_t;
+    const f2 taut = splat(a.taut), theta = splat(a.theta), one = splat(1.0f);
     unsigned long long qsum = 0ull;
 
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        sP12[wave][lane * R + r] = p12[C - 1][r];
-        sP22[wave][lane * R + r] = p22[C - 1][r];
+    f2* const rowP12 = reinterpret_cast<f2*>(&sP12[wave][lane * R]);
+    f2* const rowP22 = reinterpret_cast<f2*>(&sP22[wave][lane * R]);
+    f2* const rowU1 = reinterpret_cast<f2*>(&sU1[wave][lane * R]);
+    f2* const rowU2 = reinterpret_cast<f2*>(&sU2[wave][lane * R]);
+    const f2* const upP12 = reinterpret_cast<const f2*>(&sP12[wave > 0 ? wave - 1 : 0][lane * R]);
+    const f2* const upP22 = reinterpret_cast<const f2*>(&sP22[wave > 0 ? wave - 1 : 0][lane * R]);
+    const f2* const dnU1 = reinterpret_cast<const f2*>(&sU1[wave < NG - 1 ? wave + 1 : 0][lane * R]);
+    const f2* const dnU2 = reinterpret_cast<const f2*>(&sU2[wave < NG - 1 ? wave + 1 : 0][lane * R]);
+    const float upok = wave > 0 ? 1.0f : 0.0f, dnok = wave < NG - 1 ? 1.0f : 0.0f;
+
+#pragma clang loop unroll(full)
+    for (int j = 0; j < RP; ++j) {
+        rowP12[j] = p12[C - 1][j];
+        rowP22[j] = p22[C - 1][j];
     }
     __syncthreads();
 
     for (int k = 0; k < K; ++k) {
-        // ---- phase A: u <- TH(u) + theta * div p   (needs p of the left and upper neighbours)
-        float Lp11[C], Lp21[C], Ap12[R], Ap22[R];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            Lp11[c] = dpp_from_left(p11[c][R - 1]);
-            Lp21[c] = dpp_from_left(p21[c][R - 1]);
+        // ---- phase A: u <- TH(u) + theta * div p   (p of the left and upper neighbours)
+        // The IPOL border rules of the divergence need no selects: the left neighbour of x = 0 and
+        // the upper neighbour of y = 0 arrive as 0 (DPP bound_ctrl / wave 0), and p11 at x = w-1,
+        // p12 at y = h-1 are identically 0 (their forward differences are masked in phase B), so
+        // p - neighbour reproduces {p, -neighbour, p - neighbour} exactly.
+        f2 A12[RP], A22[RP];
+#pragma clang loop unroll(full)
+        for (int j = 0; j < RP; ++j) {
+            A12[j] = upP12[j] * upok;
+            A22[j] = upP22[j] * upok;
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            Ap12[r] = wave > 0 ? sP12[wave > 0 ? wave - 1 : 0][lane * R + r] : 0.0f;
-            Ap22[r] = wave > 0 ? sP22[wave > 0 ? wave - 1 : 0][lane * R + r] : 0.0f;
-        }
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int c = 0; c < C; ++c) {
-            const int y = y0 + c;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int x = x0 + r;
-                const float l11 = r > 0 ? p11[c][r > 0 ? r - 1 : 0] : Lp11[c];
-                const float l21 = r > 0 ? p21[c][r > 0 ? r - 1 : 0] : Lp21[c];
-                const float a12 = c > 0 ? p12[c > 0 ? c - 1 : 0][r] : Ap12[r];
-                const float a22 = c > 0 ? p22[c > 0 ? c - 1 : 0][r] : Ap22[r];
-                const float d1x = x == 0 ? p11[c][r] : (x == w - 1 ? -l11 : p11[c][r] - l11);
-                const float d1y = y == 0 ? p12[c][r] : (y == h - 1 ? -a12 : p12[c][r] - a12);
-                const float d2x = x == 0 ? p21[c][r] : (x == w - 1 ? -l21 : p21[c][r] - l21);
-                const float d2y = y == 0 ? p22[c][r] : (y == h - 1 ? -a22 : p22[c][r] - a22);
-                const float div1 = d1x + d1y, div2 = d2x + d2y;
-                const float rho = fmaf(wy[c][r], u2[c][r], fmaf(wx[c][r], u1[c][r], rc[c][r]));
-                const float fi = fminf(fmaxf(-rho * ig[c][r], -l_t), l_t);
-                const float v1 = fmaf(fi, wx[c][r], u1[c][r]);
-                const float v2 = fmaf(fi, wy[c][r], u2[c][r]);
-                const float n1 = fmaf(theta, div1, v1);
-                const float n2 = fmaf(theta, div2, v2);
+            float l11 = dpp_from_left(p11[c][RP - 1].y), l21 = dpp_from_left(p21[c][RP - 1].y);
+            if constexpr (LX != 64) {
+                l11 *= lfix;
+                l21 *= lfix;
+            }
+#pragma clang loop unroll(full)
+            for (int j = 0; j < RP; ++j) {
+                const f2 L11 = f2{j > 0 ? p11[c][j > 0 ? j - 1 : 0].y : l11, p11[c][j].x};
+                const f2 L21 = f2{j > 0 ? p21[c][j > 0 ? j - 1 : 0].y : l21, p21[c][j].x};
+                const f2 a12 = c > 0 ? p12[c > 0 ? c - 1 : 0][j] : A12[j];
+                const f2 a22 = c > 0 ? p22[c > 0 ? c - 1 : 0][j] : A22[j];
+                const f2 div1 = (p11[c][j] - L11) + (p12[c][j] - a12);
+                const f2 div2 = (p21[c][j] - L21) + (p22[c][j] - a22);
+                const f2 rho = pk_fma(wy[c][j], u2[c][j], pk_fma(wx[c][j], u1[c][j], rc[c][j]));
+                const f2 t = -rho * ig[c][j];
+                const f2 fi = f2{__builtin_amdgcn_fmed3f(t.x, -l_t, l_t), __builtin_amdgcn_fmed3f(t.y, -l_t, l_t)};
+                const f2 v1 = pk_fma(fi, wx[c][j], u1[c][j]);
+                const f2 v2 = pk_fma(fi, wy[c][j], u2[c][j]);
+                const f2 n1 = pk_fma(theta, div1, v1);
+                const f2 n2 = pk_fma(theta, div2, v2);
                 if constexpr (EPS) {
-                    if (x >= vx0 && x < vx1 && y >= vy0 && y < vy1) {
-                        const float e1 = n1 - u1[c][r], e2 = n2 - u2[c][r];
-                        const float e = fmaf(e2, e2, e1 * e1);
-                        qsum += (unsigned long long)(fminf(e, 1024.0f) * 4294967296.0f);
+                    const int y = y0 + c, x = x0 + 2 * j;
+                    const f2 e1 = n1 - u1[c][j], e2 = n2 - u2[c][j];
+                    const f2 e = pk_fma(e2, e2, e1 * e1);
+                    if (y >= vy0 && y < vy1) {
+                        if (x >= vx0 && x < vx1) qsum += (unsigned long long)(fminf(e.x, 1024.0f) * 4294967296.0f);
+                        if (x + 1 >= vx0 && x + 1 < vx1) qsum += (unsigned long long)(fminf(e.y, 1024.0f) * 4294967296.0f);
                     }
                 }
-                u1[c][r] = n1;
-                u2[c][r] = n2;
+                u1[c][j] = n1;
+                u2[c][j] = n2;
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep rows in program order: bounds register pressure
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            sU1[wave][lane * R + r] = u1[0][r];
-            sU2[wave][lane * R + r] = u2[0][r];
+#pragma clang loop unroll(full)
+        for (int j = 0; j < RP; ++j) {
+            rowU1[j] = u1[0][j];
+            rowU2[j] = u2[0][j];
         }
         __syncthreads();
 
         // ---- phase B: p <- (p + taut * grad u) / (1 + taut * |grad u|)   (right and lower neighbours)
-        float Ru1[C], Ru2[C], Bu1[R], Bu2[R];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            Ru1[c] = dpp_from_right(u1[c][0]);
-            Ru2[c] = dpp_from_right(u2[c][0]);
+        f2 B1[RP], B2[RP];
+#pragma clang loop unroll(full)
+        for (int j = 0; j < RP; ++j) {
+            B1[j] = dnU1[j] * dnok;
+            B2[j] = dnU2[j] * dnok;
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            Bu1[r] = wave < NW - 1 ? sU1[wave < NW - 1 ? wave + 1 : 0][lane * R + r] : 0.0f;
-            Bu2[r] = wave < NW - 1 ? sU2[wave < NW - 1 ? wave + 1 : 0][lane * R + r] : 0.0f;
-        }
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int c = 0; c < C; ++c) {
-            const int y = y0 + c;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int x = x0 + r;
-                const float r1 = r < R - 1 ? u1[c][r < R - 1 ? r + 1 : 0] : Ru1[c];
-                const float r2 = r < R - 1 ? u2[c][r < R - 1 ? r + 1 : 0] : Ru2[c];
-                const float b1 = c < C - 1 ? u1[c < C - 1 ? c + 1 : 0][r] : Bu1[r];
-                const float b2 = c < C - 1 ? u2[c < C - 1 ? c + 1 : 0][r] : Bu2[r];
-                const float u1x = x < w - 1 ? r1 - u1[c][r] : 0.0f;
-                const float u1y = y < h - 1 ? b1 - u1[c][r] : 0.0f;
-                const float u2x = x < w - 1 ? r2 - u2[c][r] : 0.0f;
-                const float u2y = y < h - 1 ? b2 - u2[c][r] : 0.0f;
-                const float g1 = sqrtf(fmaf(u1y, u1y, u1x * u1x));
-                const float g2 = sqrtf(fmaf(u2y, u2y, u2x * u2x));
-                const float q1 = 1.0f / fmaf(taut, g1, 1.0f);
-                const float q2 = 1.0f / fmaf(taut, g2, 1.0f);
-                p11[c][r] = fmaf(taut, u1x, p11[c][r]) * q1;
-                p12[c][r] = fmaf(taut, u1y, p12[c][r]) * q1;
-                p21[c][r] = fmaf(taut, u2x, p21[c][r]) * q2;
-                p22[c][r] = fmaf(taut, u2y, p22[c][r]) * q2;
+            const float r1 = dpp_from_right(u1[c][0].x), r2 = dpp_from_right(u2[c][0].x);
+#pragma clang loop unroll(full)
+            for (int j = 0; j < RP; ++j) {
+                const f2 R1 = f2{u1[c][j].y, j < RP - 1 ? u1[c][j < RP - 1 ? j + 1 : 0].x : r1};
+                const f2 R2 = f2{u2[c][j].y, j < RP - 1 ? u2[c][j < RP - 1 ? j + 1 : 0].x : r2};
+                const f2 b1 = c < C - 1 ? u1[c < C - 1 ? c + 1 : 0][j] : B1[j];
+                const f2 b2 = c < C - 1 ? u2[c < C - 1 ? c + 1 : 0][j] : B2[j];
+                const f2 u1x = (R1 - u1[c][j]) * mx[j], u1y = (b1 - u1[c][j]) * my[c];
+                const f2 u2x = (R2 - u2[c][j]) * mx[j], u2y = (b2 - u2[c][j]) * my[c];
+                const f2 s1 = pk_fma(u1y, u1y, u1x * u1x), s2 = pk_fma(u2y, u2y, u2x * u2x);
+                f2 q1, q2;
+                if constexpr (FAST) {  // 1-ulp hardware sqrt / rcp (va_tvl1_params.fast_math)
+                    const f2 g1 = f2{__builtin_amdgcn_sqrtf(s1.x), __builtin_amdgcn_sqrtf(s1.y)};
+                    const f2 g2 = f2{__builtin_amdgcn_sqrtf(s2.x), __builtin_amdgcn_sqrtf(s2.y)};
+                    const f2 d1 = pk_fma(taut, g1, one), d2 = pk_fma(taut, g2, one);
+                    q1 = f2{__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)};
+                    q2 = f2{__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)};
+                } else {
+                    // exact contract: correctly rounded sqrt, ONE correctly rounded division per pixel.
+                    // s + 2^-100 keeps the argument in sqrt_exact_pk's domain and never changes
+                    // d = fma(taut, sqrt(s), 1): it alters s only below 1.3e-23, where taut*sqrt(s)
+                    // < 2^-25 (taut <= 1000 is checked on the host) and d rounds to 1 either way.
+                    const f2 g1 = sqrt_exact_pk(s1 + kSqrtReg), g2 = sqrt_exact_pk(s2 + kSqrtReg);
+                    const f2 d1 = pk_fma(taut, g1, one), d2 = pk_fma(taut, g2, one);
+                    const f2 rinv = rcp_exact_pk(d1 * d2);
+                    q1 = d2 * rinv;
+                    q2 = d1 * rinv;
+                }
+                p11[c][j] = pk_fma(taut, u1x, p11[c][j]) * q1;
+                p12[c][j] = pk_fma(taut, u1y, p12[c][j]) * q1;
+                p21[c][j] = pk_fma(taut, u2x, p21[c][j]) * q2;
+                p22[c][j] = pk_fma(taut, u2y, p22[c][j]) * q2;
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            sP12[wave][lane * R + r] = p12[C - 1][r];
-            sP22[wave][lane * R + r] = p22[C - 1][r];
+#pragma clang loop unroll(full)
+        for (int j = 0; j < RP; ++j) {
+            rowP12[j] = p12[C - 1][j];
+            rowP22[j] = p22[C - 1][j];
         }
         __syncthreads();
     }
 
     // ---- write back the tile's valid interior (the valid regions partition the image)
     const bool runok = x0 >= vx0 && x0 < vx1;
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int c = 0; c < C; ++c) {
         const int y = y0 + c;
         if (runok && y >= vy0 && y < vy1 && y < h) {
             const size_t ro_ = (size_t)y * pitch;
-            store_run<R>(sout + ro_, x0, pitch, u1[c]);
-            store_run<R>(sout + a.plane + ro_, x0, pitch, u2[c]);
-            store_run<R>(sout + 2 * a.plane + ro_, x0, pitch, p11[c]);
-            store_run<R>(sout + 3 * a.plane + ro_, x0, pitch, p12[c]);
-            store_run<R>(sout + 4 * a.plane + ro_, x0, pitch, p21[c]);
-            store_run<R>(sout + 5 * a.plane + ro_, x0, pitch, p22[c]);
+            store_row<RP>(sout + ro_, x0, pitch, u1[c]);
+            store_row<RP>(sout + a.plane + ro_, x0, pitch, u2[c]);
+            store_row<RP>(sout + 2 * a.plane + ro_, x0, pitch, p11[c]);
+            store_row<RP>(sout + 3 * a.plane + ro_, x0, pitch, p12[c]);
+            store_row<RP>(sout + 4 * a.plane + ro_, x0, pitch, p21[c]);
+            store_row<RP>(sout + 5 * a.plane + ro_, x0, pitch, p22[c]);
         }
     }
     if constexpr (EPS) {
@@ -458,10 +529,11 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
 // ---------------------------------------------------------------- host side -------------------
 
 struct TileCfg {
-    int R, C, NW;
+    int R, C, NW, LX;
 };
-// Candidate tilings: ~16 pixels per thread, 512-thread workgroups (2 waves per SIMD).
-constexpr TileCfg kCfgs[] = {{4, 4, 8}, {3, 5, 8}, {2, 8, 8}};
+// Candidate tilings (R, C, NW, LX): 256x32 and 128x64 tiles, 512 threads, a 4x4 pixel patch per thread
+// (the packed-math kernel needs more than the 128 VGPRs a 1024-thread workgroup would leave it).
+constexpr TileCfg kCfgs[] = {{4, 4, 8, 64}, {4, 4, 8, 32}};
 
 struct TilePick {
     int cfg, ntx, nty, HX, K;
@@ -479,10 +551,10 @@ TilePick pick_tiles(int w, int h, int K)
     TilePick best{};
     double best_cost = 1e300;
     for (int i = 0; i < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++i) {
-        const int R = kCfgs[i].R, TW = 64 * R, TH = kCfgs[i].NW * kCfgs[i].C;
+        const int R = kCfgs[i].R, TW = kCfgs[i].LX * R, TH = kCfgs[i].NW * (64 / kCfgs[i].LX) * kCfgs[i].C;
         int k = K;
         if (h > TH && 2 * k >= TH) k = (TH - 1) / 2 > 0 ? (TH - 1) / 2 : 1;
-        const int align = (R == 4 || R == 2) ? 4 : R;  // tile origins stay vector-aligned
+        const int align = 4;  // tile origins stay 16-byte aligned
         int HX = 0;
         if (w > TW) {
             HX = va_cdiv(k, align) * align;
@@ -500,14 +572,13 @@ TilePick pick_tiles(int w, int h, int K)
     return best;
 }
 
-template <bool EPS>
+template <bool EPS, bool FAST>
 void launch_iter(const TilePick& tp, const IterArgs& a, int npairs, hipStream_t st)
 {
     const dim3 grid(tp.ntx * tp.nty, npairs);
     switch (tp.cfg) {
-        case 0: k_iter_tile<4, 4, 8, EPS><<<grid, 512, 0, st>>>(a); break;
-        case 1: k_iter_tile<3, 5, 8, EPS><<<grid, 512, 0, st>>>(a); break;
-        default: k_iter_tile<2, 8, 8, EPS><<<grid, 512, 0, st>>>(a); break;
+        case 0: k_iter_tile<2, 4, 8, 64, EPS, FAST><<<grid, 512, 0, st>>>(a); break;   // 256 x 32 tile
+        default: k_iter_tile<2, 4, 8, 32, EPS, FAST><<<grid, 512, 0, st>>>(a); break;  // 128 x 64 tile (folded waves)
     }
 }
 
@@ -543,6 +614,8 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
     VA_CHECK_ARG(p->scale_step > 0.0f && p->scale_step < 1.0f, "va_tvl1: scale_step must be in (0,1)");
     VA_CHECK_ARG(p->tau > 0.0f && p->lambda > 0.0f && p->theta > 0.0f, "va_tvl1: tau, lambda, theta must be > 0");
     VA_CHECK_ARG(p->block_iters >= 0 && p->block_iters <= 64, "va_tvl1: block_iters must be in [0,64]");
+    VA_CHECK_ARG(p->fast_math == 0 || p->fast_math == 1, "va_tvl1: fast_math must be 0 or 1");
+    VA_CHECK_ARG(p->tau / p->theta <= 1000.0f && p->lambda * p->theta <= 1000.0f, "va_tvl1: tau/theta and lambda*theta must be <= 1000");
     return VA_OK;
 }
 
@@ -618,6 +691,7 @@ extern "C" void va_tvl1_default_params(va_tvl1_params* p)
     p->iters = 300;
     p->scale_step = 0.8f;
     p->block_iters = 0;
+    p->fast_math = 0;
 }
 
 extern "C" int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* hs)
@@ -743,8 +817,13 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                 a.cur = cur;
                 a.K = tk.K;
                 a.it = it;
-                if (eps) launch_iter<true>(tk, a, P.NP, st);
-                else launch_iter<false>(tk, a, P.NP, st);
+                if (eps) {
+                    if (p->fast_math) launch_iter<true, true>(tk, a, P.NP, st);
+                    else launch_iter<true, false>(tk, a, P.NP, st);
+                } else {
+                    if (p->fast_math) launch_iter<false, true>(tk, a, P.NP, st);
+                    else launch_iter<false, false>(tk, a, P.NP, st);
+                }
                 cur ^= 1;
                 it += tk.K;
                 ++launches;
@@ -786,6 +865,19 @@ extern "C" int va_flow_to_stack(va_ctx* ctx, const void* flow, int n_pairs, int 
     VA_CHECK_ARG(bound > 0.0f && stdv > 0.0f, "va_flow_to_stack: bound and std must be > 0");
     const size_t n = (size_t)n_pairs * 2 * w * h;
     k_flow_to_stack<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>((const float*)flow, (float*)stack, n, bound, mean, stdv);
+    VA_LAUNCH_CHECK();
+    return VA_OK;
+}
+
+extern "C" int va_selftest_exact_math(va_ctx* ctx, float lo, float hi, unsigned long long* mismatches, void* stream)
+{
+    VA_CHECK_ARG(ctx != nullptr && mismatches != nullptr, "va_selftest_exact_math: NULL argument");
+    VA_CHECK_ARG(lo >= kSqrtReg && hi <= 1e30f && lo <= hi, "va_selftest_exact_math: range must lie in [2^-100, 1e30]");
+    unsigned ulo, uhi;
+    memcpy(&ulo, &lo, 4);
+    memcpy(&uhi, &hi, 4);
+    VA_HIP(hipMemsetAsync(mismatches, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream));
+    k_selftest_exact_math<<<4096, 256, 0, (hipStream_t)stream>>>(ulo, (unsigned long long)uhi - ulo + 1, mismatches);
     VA_LAUNCH_CHECK();
     return VA_OK;
 }
