@@ -180,3 +180,38 @@ def test_datasets_read_the_reference_directory_layout(tmp_path):
     assert v.shape == (20, 224, 224) and label == 1 and name == "v_Archery_g01_c01"
     with pytest.raises(ValueError):
         SpatialDataset(str(lst), str(tmp_path / "frames"), tf, mode="test")  # no label file: Sheet03/spatialModel.py:46
+
+
+def test_flow_images_follow_the_reference_file_layout(tmp_path):
+    from PIL import Image
+    flow = torch.tensor([[-25.0, -20.0, 0.0], [20.0, 30.0, 0.07843]]).reshape(1, 2, 1, 3).repeat(3, 1, 8, 4)
+    q = U.flowToImages(flow)
+    assert q.dtype == np.uint8 and q.shape == (3, 2, 8, 12)
+    assert q[0, 0, 0, :3].tolist() == [0, 0, 128] and q[0, 1, 0, :3].tolist() == [255, 255, 128]
+    d = str(tmp_path / "Archery" / "v_Archery_g01_c01")
+    assert U.saveFlowImages(flow, d) == 6
+    names = sorted(os.listdir(d))
+    assert names == ["flow_x_0001.jpg", "flow_x_0002.jpg", "flow_x_0003.jpg", "flow_y_0001.jpg", "flow_y_0002.jpg", "flow_y_0003.jpg"]
+    im = Image.open(os.path.join(d, "flow_y_0002.jpg"))
+    assert im.mode == "L" and im.size == (12, 8)
+    assert np.abs(np.asarray(im).astype(int) - q[1, 1].astype(int)).max() <= 6  # JPEG is lossy
+    # the reference's index arithmetic on this directory: 6 files -> nFlows = 3
+    assert U.temporalFlowIndices(len(names), 2, r=1)[1] == [("x", 1), ("y", 1), ("x", 2), ("y", 2)]
+
+
+def test_weights_from_reference_style_state_dict():
+    from video_analytics_amd import vgg
+    cfg = [(0, 3, 64), (2, 64, 64), (5, 64, 128), (7, 128, 128), (10, 128, 256), (12, 256, 256), (14, 256, 256),
+           (17, 256, 512), (19, 512, 512), (21, 512, 512), (24, 512, 512), (26, 512, 512), (28, 512, 512)]
+    sd = {}
+    for i, ci, co in cfg:
+        sd["module.features.%d.weight" % i] = torch.zeros(co, ci, 3, 3)
+        sd["module.features.%d.bias" % i] = torch.full((co,), float(i))
+    for i, (fo, fi) in zip([0, 3, 6, 9], [(4096, 25088), (4096, 4096), (256, 4096), (101, 256)]):
+        sd["module.classifier.%d.weight" % i] = torch.zeros(1, 1).expand(fo, fi)
+        sd["module.classifier.%d.bias" % i] = torch.zeros(fo)
+    w = vgg.weights_from_state_dict(sd)
+    assert [tuple(t.shape) for t in w["conv_w"]][4] == (256, 128, 3, 3) and float(w["conv_b"][12][0]) == 28.0
+    assert tuple(w["fc_w"][2].shape) == (256, 4096) and len(w["fc_b"]) == 4
+    with pytest.raises(ValueError):
+        vgg.weights_from_state_dict({"features.0.weight": torch.zeros(1)})

@@ -133,3 +133,23 @@ def test_full_batch_properties():
     assert torch.equal(one["logits_s"][0], out["logits_s"][9]) and torch.equal(one["logits_t"][0], out["logits_t"][9])
     assert bool(torch.isfinite(out["logits_t"]).all())
     pipe.close()
+
+
+def test_sharded_sweep_equals_single_batch_results():
+    """BASELINE config 4 logic at world_size 1: a 70-clip sweep in batches of 32 (ragged last batch)
+    returns, in global clip order, exactly the scores of running those clips directly."""
+    from video_analytics_amd import _ffi, pipeline, sweep, synth
+    pipe = pipeline.TwoStreamPipeline(device=0, tvl1_params=_ffi.default_tvl1_params(epsilon=0.0, iters=10, warps=1, nscales=2))
+
+    def make_batch(lo, hi):
+        rgb, gray, _ = synth.synth_clips(hi - lo, seed=4, first_clip=lo)
+        return rgb.cuda(), gray.cuda()
+
+    scores = sweep.run_sweep(pipe, 70, make_batch, batch_size=32)
+    assert scores.shape == (70, 2, 101)
+    rgb, gray = make_batch(64, 70)
+    ref = pipe.run_batch(rgb, gray)
+    assert torch.equal(scores[64:70, 0], ref["logits_s"]) and torch.equal(scores[64:70, 1], ref["logits_t"])
+    acc = sweep.score(scores, scores[:, 0].argmax(1))
+    assert acc["spatial"] == 1.0 and 0.0 <= acc["fused"] <= 1.0
+    pipe.close()

@@ -97,6 +97,14 @@ def test_fast_math_mode_within_tolerance_and_tiling_independent(oracle_tvl1):
     assert d.max() > 0.0  # it really is a different arithmetic
 
 
+def test_hd_pair_full_schedule_bit_exact(oracle_tvl1):
+    # BASELINE config 3 at its full size and schedule: 1280x720, 5 scales x 5 warps x 300 iterations
+    # (3.4e9 pixel-iterations; the single-threaded C oracle needs ~15 s for it)
+    gray = _frames(1, 2, 720, 1280, seed=3)
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
 def test_u8_and_f32_frames_agree():
     from video_analytics_amd import flow as vflow
     gray = _frames(1, 3, 64, 80, seed=2)

@@ -93,6 +93,31 @@ def flowFileName(prefix, idx, extn=".jpg"):
     return prefix + str(idx).zfill(4) + extn
 
 
+def flowToImages(flow, bound=20.0):
+    """flow ``[N,2,H,W]`` float32 (torch or numpy) -> uint8 ``[N,2,H,W]``: the 8-bit flow image
+    convention the reference's flow JPEGs follow, ``q = rint(clamp(255*(v+bound)/(2*bound), 0, 255))``
+    (the quantisation step of ``va_flow_to_stack``)."""
+    f = flow.detach().cpu().numpy() if isinstance(flow, torch.Tensor) else np.asarray(flow)
+    f = f.astype(np.float32)
+    t = (np.float32(255.0) * (f + np.float32(bound))) / np.float32(2.0 * bound)
+    return np.rint(np.clip(t, 0.0, 255.0)).astype(np.uint8)
+
+
+def saveFlowImages(flow, flowDir, bound=20.0, firstIndex=1, quality=95):
+    """Write the flow of the N consecutive pairs of one video as the files the reference reads:
+    ``flow_x_%04d.jpg`` / ``flow_y_%04d.jpg``, 1-based, single-channel 'L' JPEGs
+    (Sheet03/temporalModel.py:78-81, Sheet03/parameters.py:38-39).  Returns the file count."""
+    from PIL import Image
+    from .parameters import FRAME_EXTN, X_PREFIX_FLOW, Y_PREFIX_FLOW
+    checkAndMakeDirectories(flowDir)
+    q = flowToImages(flow, bound)
+    for k in range(q.shape[0]):
+        for prefix, plane in ((X_PREFIX_FLOW, 0), (Y_PREFIX_FLOW, 1)):
+            Image.fromarray(q[k, plane], mode="L").save(os.path.join(flowDir, flowFileName(prefix, firstIndex + k, FRAME_EXTN)),
+                                                         quality=quality)
+    return 2 * q.shape[0]
+
+
 # ----------------------------------------------------------------------------- transforms ------
 
 class RandomCrop(object):

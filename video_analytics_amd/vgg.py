@@ -152,6 +152,25 @@ class Vgg16Stream(object):
         return desc, logits
 
 
+def weights_from_state_dict(state_dict):
+    """Weights of a torchvision-style VGG-16 state dict as saved by the reference
+    (``checkpoint["model"]``, Sheet03/spatialModel.py:256-261; keys carry the ``module.`` prefix of the
+    ``nn.DataParallel`` wrapper, ``:133,258``): ``features.{0,2,5,...}.weight/bias`` and
+    ``classifier.{0,3,6,9}.weight/bias`` -> dict(conv_w, conv_b, fc_w, fc_b)."""
+    sd = {}
+    for k, v in state_dict.items():
+        sd[k[len("module."):] if k.startswith("module.") else k] = v
+    conv_idx = [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]  # Conv2d positions in VGG-16 'D' features
+    fc_idx = [0, 3, 6, 9]                                          # Linear positions in the swapped classifier
+    try:
+        return dict(conv_w=[sd["features.%d.weight" % i] for i in conv_idx],
+                    conv_b=[sd["features.%d.bias" % i] for i in conv_idx],
+                    fc_w=[sd["classifier.%d.weight" % i] for i in fc_idx],
+                    fc_b=[sd["classifier.%d.bias" % i] for i in fc_idx])
+    except KeyError as e:
+        raise ValueError("weights_from_state_dict: missing key %s (not a VGG-16 'D' + 4-layer classifier state dict)" % e)
+
+
 def _ffi_conv_cout(i):
     return (64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512)[i]
 
