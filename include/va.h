@@ -161,7 +161,10 @@ int va_selftest_exact_math(va_ctx* ctx, float lo, float hi, unsigned long long* 
  * those events and returns, summed over all va_tvl1_flow calls since the last reset:
  * out[0] = milliseconds inside the inner-iteration kernel, out[1] = its launches,
  * out[2] = pixel-iterations it performed (valid pixels x iterations; algorithmic bytes =
- * 64 B x out[2]), out[3] = pixel-warps (44 B each) -- all as doubles (HOST array of 4).
+ * 64 B x out[2]), out[3] = pixel-warps (44 B each), out[4] = milliseconds during which at least one
+ * run of inner-iteration launches was in flight (the union of the bracketed intervals: equals
+ * out[0] on one stream, smaller when calls on several streams overlap) -- all as doubles (HOST
+ * array of 5).  va_tvl1_profile_enable(1) synchronises the device and sets the time origin.
  */
 int va_tvl1_profile_enable(va_ctx* ctx, int on);
 int va_tvl1_profile_read(va_ctx* ctx, double* out, int reset);

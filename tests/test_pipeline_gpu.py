@@ -135,6 +135,20 @@ def test_full_batch_properties():
     pipe.close()
 
 
+def test_concurrent_flow_streams_give_identical_results():
+    from video_analytics_amd import flow as vflow, synth
+    _, gray, _ = synth.synth_clips(5, seed=6, n_gray=4)
+    g = gray.cuda()
+    p = dict(epsilon=0.0, iters=30, warps=2)
+    from video_analytics_amd import _ffi
+    ref = vflow.tvl1_flow(g, _ffi.default_tvl1_params(**p))
+    for n in (2, 3, 8):
+        out = vflow.tvl1_flow_concurrent(g, _ffi.default_tvl1_params(**p), n_streams=n)
+        assert out.shape == ref.shape and torch.equal(out, ref)
+    eps = vflow.tvl1_flow_concurrent(g, _ffi.default_tvl1_params(epsilon=0.01), n_streams=2)
+    assert torch.equal(eps, vflow.tvl1_flow(g, _ffi.default_tvl1_params(epsilon=0.01)))
+
+
 def test_sharded_sweep_equals_single_batch_results():
     """BASELINE config 4 logic at world_size 1: a 70-clip sweep in batches of 32 (ragged last batch)
     returns, in global clip order, exactly the scores of running those clips directly."""

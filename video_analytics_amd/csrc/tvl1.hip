@@ -23,7 +23,9 @@
 // algorithmic 64 B to about 64 B / K / tile_efficiency.
 #include "va_internal.h"
 #include <cmath>
+#include <algorithm>
 #include <cstring>
+#include <utility>
 
 namespace {
 
@@ -886,24 +888,51 @@ extern "C" int va_tvl1_profile_enable(va_ctx* ctx, int on)
 {
     VA_CHECK_ARG(ctx != nullptr, "va_tvl1_profile_enable: ctx is NULL");
     ctx->prof_on = on != 0;
+    if (on) {
+        // time origin: everything recorded later (on any stream) is measured against it
+        if (!ctx->prof_ref) VA_HIP(hipEventCreate(&ctx->prof_ref));
+        VA_HIP(hipDeviceSynchronize());
+        VA_HIP(hipEventRecord(ctx->prof_ref, nullptr));
+        VA_HIP(hipEventSynchronize(ctx->prof_ref));
+    }
     return VA_OK;
 }
 
 extern "C" int va_tvl1_profile_read(va_ctx* ctx, double* out, int reset)
 {
     VA_CHECK_ARG(ctx != nullptr && out != nullptr, "va_tvl1_profile_read: NULL argument");
+    std::vector<std::pair<float, float>> iv;
     for (va_prof_span& s : ctx->prof_spans) {
         VA_HIP(hipEventSynchronize(s.end));
-        float ms = 0.0f;
+        float ms = 0.0f, t0 = 0.0f, t1 = 0.0f;
         VA_HIP(hipEventElapsedTime(&ms, s.beg, s.end));
         ctx->prof_ms += ms;
+        if (ctx->prof_ref) {
+            VA_HIP(hipEventElapsedTime(&t0, ctx->prof_ref, s.beg));
+            VA_HIP(hipEventElapsedTime(&t1, ctx->prof_ref, s.end));
+            iv.emplace_back(t0, t1);
+        }
         ctx->prof_pool.push_back(s);
     }
     ctx->prof_spans.clear();
+    // union of the spans: with several streams the launches of different calls overlap in time
+    std::sort(iv.begin(), iv.end());
+    float cur0 = 0.0f, cur1 = -1.0f;
+    for (auto& p : iv) {
+        if (cur1 < cur0 || p.first > cur1) {
+            if (cur1 >= cur0) ctx->prof_union_ms += cur1 - cur0;
+            cur0 = p.first;
+            cur1 = p.second;
+        } else if (p.second > cur1) {
+            cur1 = p.second;
+        }
+    }
+    if (cur1 >= cur0) ctx->prof_union_ms += cur1 - cur0;
     out[0] = ctx->prof_ms;
     out[1] = ctx->prof_launches;
     out[2] = ctx->prof_pxiters;
     out[3] = ctx->prof_pxwarps;
-    if (reset) ctx->prof_ms = ctx->prof_launches = ctx->prof_pxiters = ctx->prof_pxwarps = 0.0;
+    out[4] = ctx->prof_union_ms;
+    if (reset) ctx->prof_ms = ctx->prof_union_ms = ctx->prof_launches = ctx->prof_pxiters = ctx->prof_pxwarps = 0.0;
     return VA_OK;
 }

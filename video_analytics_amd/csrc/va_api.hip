@@ -34,7 +34,8 @@ extern "C" int va_ctx_create(int device, va_ctx** out)
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
     c->prof_on = false;
-    c->prof_ms = c->prof_launches = c->prof_pxiters = c->prof_pxwarps = 0.0;
+    c->prof_ref = nullptr;
+    c->prof_ms = c->prof_union_ms = c->prof_launches = c->prof_pxiters = c->prof_pxwarps = 0.0;
     *out = c;
     return VA_OK;
 }
@@ -50,5 +51,6 @@ extern "C" void va_ctx_destroy(va_ctx* ctx)
         hipEventDestroy(s.beg);
         hipEventDestroy(s.end);
     }
+    if (ctx->prof_ref) hipEventDestroy(ctx->prof_ref);
     delete ctx;
 }

@@ -17,7 +17,8 @@ struct va_ctx {
     bool prof_on;
     std::vector<va_prof_span> prof_spans;  // recorded, not yet read
     std::vector<va_prof_span> prof_pool;   // reusable events
-    double prof_ms, prof_launches, prof_pxiters, prof_pxwarps;
+    hipEvent_t prof_ref;                   // time origin for the union of spans (several streams)
+    double prof_ms, prof_union_ms, prof_launches, prof_pxiters, prof_pxwarps;
 };
 
 void va_set_error(const char* fmt, ...);

@@ -23,7 +23,9 @@ def init(backend=None):
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # VA_DIST_BACKEND=gloo is a rehearsal hook: several ranks on ONE GPU box (RCCL refuses
+            # two ranks on the same device); production is nccl = RCCL over xGMI.
+            backend = os.environ.get("VA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -63,7 +65,13 @@ def gather_scores(local, n_items, world=None):
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad.contiguous())
+    if dist.get_backend() == "gloo" and out.is_cuda:
+        # gloo has no CUDA all_gather_into_tensor: stage through the host (rehearsal only)
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, pad.cpu().contiguous())
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, pad.contiguous())
     return out[:n_items]
 
 
@@ -76,6 +84,8 @@ def max_over_ranks(value, device):
     """Max of a Python float over all ranks (used for the benchmark's max-over-ranks timing)."""
     if not dist.is_initialized():
         return value
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

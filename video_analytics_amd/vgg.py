@@ -13,8 +13,9 @@ from . import _ffi
 _ws_cache = {}
 
 
-def _workspace(nbytes, device):
-    key = (device.index, "vgg")
+def _workspace(nbytes, device, slot=0):
+    """Grow-only workspace per (device, slot); models that may run concurrently use different slots."""
+    key = (device.index, "vgg", slot)
     t = _ws_cache.get(key)
     if t is None or t.numel() < nbytes:
         _ws_cache[key] = t = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -41,11 +42,13 @@ class Vgg16Stream(object):
     """VGG-16 'D' features + Linear(25088,4096)/ReLU/Linear(4096,4096)/ReLU/Linear(4096,D)/ReLU/
     Linear(D,nClasses), weights packed once for the gfx950 kernels."""
 
-    def __init__(self, conv_w, conv_b, fc_w, fc_b, n_classes, desc_dim, in_mean=None, in_std=None, device=None):
+    def __init__(self, conv_w, conv_b, fc_w, fc_b, n_classes, desc_dim, in_mean=None, in_std=None, device=None,
+                 ws_slot=0):
         if len(conv_w) != 13 or len(conv_b) != 13 or len(fc_w) != 4 or len(fc_b) != 4:
             raise ValueError("Vgg16Stream: need 13 conv and 4 fc weight/bias tensors")
         dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.device = dev
+        self.ws_slot = ws_slot
         self.c_in = int(conv_w[0].shape[1])
         self.n_classes = int(n_classes)
         self.desc_dim = int(desc_dim)
@@ -110,7 +113,7 @@ class Vgg16Stream(object):
         B = x.shape[0]
         L = _ffi.lib()
         nbytes = L.va_vgg16_workspace_bytes(self._h, B)
-        ws = _workspace(nbytes, x.device)
+        ws = _workspace(nbytes, x.device, self.ws_slot)
         feat = torch.empty((B, 512, 7, 7), dtype=torch.float32, device=x.device) if want_feat else None
         desc = torch.empty((B, self.desc_dim), dtype=torch.float32, device=x.device)
         logits = torch.empty((B, self.n_classes), dtype=torch.float32, device=x.device)
@@ -128,7 +131,7 @@ class Vgg16Stream(object):
         x = x.contiguous()
         B = x.shape[0]
         L = _ffi.lib()
-        ws = _workspace(L.va_vgg16_workspace_bytes(self._h, B), x.device)
+        ws = _workspace(L.va_vgg16_workspace_bytes(self._h, B), x.device, self.ws_slot)
         feat = torch.empty((B, 512, 7, 7), dtype=torch.float32, device=x.device)
         _ffi.check(L.va_vgg16_forward(self._h, _ffi.ptr(x), int(x.dtype == torch.uint8), B, _ffi.ptr(feat), None, None,
                                       _ffi.ptr(ws), ws.numel(), _ffi.stream_ptr()))
@@ -144,7 +147,7 @@ class Vgg16Stream(object):
         feat = feat.contiguous()
         B = feat.shape[0]
         L = _ffi.lib()
-        ws = _workspace(L.va_vgg16_workspace_bytes(self._h, B), feat.device)
+        ws = _workspace(L.va_vgg16_workspace_bytes(self._h, B), feat.device, self.ws_slot)
         desc = torch.empty((B, self.desc_dim), dtype=torch.float32, device=feat.device)
         logits = torch.empty((B, self.n_classes), dtype=torch.float32, device=feat.device)
         _ffi.check(L.va_vgg16_classify(self._h, _ffi.ptr(feat), B, _ffi.ptr(desc), _ffi.ptr(logits), _ffi.ptr(ws),
