@@ -564,11 +564,37 @@ TilePick pick_tiles(int w, int h, int K)
         }
         const int ntx = tiles_1d(w, TW, HX), nty = tiles_1d(h, TH, k);
         const long slots = (long)ntx * nty * TW * TH;
-        // cost ~ slots * (compute per iteration + memory amortised over k)
-        const double cost = (double)slots * (1.0 + 8.0 / k);
+        // measured on MI355X (profiles/README.md): an 8192-pixel tile costs ~12 us of exposed HBM round
+        // trip per launch plus ~2.9 us per inner iteration; cost per iteration of this level:
+        const double cost = (double)slots / 8192.0 * (12.0 / k + 2.9);
         if (cost < best_cost) {
             best_cost = cost;
             best = TilePick{i, ntx, nty, HX, k};
+        }
+    }
+    return best;
+}
+
+// block_iters = 0: the depth K that minimises the modelled time of one warp's `iters` iterations
+// (full launches of K plus one shorter launch for the remainder).
+TilePick pick_tiles_auto(int w, int h, int iters)
+{
+    TilePick best{};
+    double best_cost = 1e300;
+    for (int K = 1; K <= 31 && K <= iters; ++K) {
+        const TilePick tp = pick_tiles(w, h, K);
+        if (tp.K != K) continue;
+        const int full = iters / K, rem = iters - full * K;
+        const int TWTH = 8192;
+        double cost = (double)full * tp.ntx * tp.nty * (12.0 + 2.9 * K);
+        if (rem) {
+            const TilePick tr = pick_tiles(w, h, rem);
+            cost += (double)tr.ntx * tr.nty * (12.0 + 2.9 * tr.K) * ((double)rem / tr.K);
+        }
+        (void)TWTH;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = tp;
         }
     }
     return best;
@@ -769,13 +795,13 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
     VA_HIP(hipMemsetAsync(state[0], 0, (size_t)P.NP * kNF_STATE * P.plane[sc] * sizeof(float), st));
     VA_HIP(hipMemsetAsync(sel, 0, (size_t)P.NP * 2 * sizeof(int), st));
     int cur = 0;
-    int K0 = p->block_iters > 0 ? p->block_iters : 12;  // measured optimum on MI355X at 224x224 (profiles/)
+    int K0 = p->block_iters;  // 0 = per-level automatic choice (12 on every level of the 224x224 pyramid's top three)
     if (eps) K0 = 1;
 
     for (int s = sc; s >= 0; --s) {
         const int lw = P.ws[s], lh = P.hs[s], lp = P.pitch[s];
         const size_t plane = P.plane[s];
-        const TilePick tp = pick_tiles(lw, lh, K0);
+        const TilePick tp = K0 > 0 ? pick_tiles(lw, lh, K0) : pick_tiles_auto(lw, lh, p->iters);
         const dim3 gpx(va_cdiv(lw * lh, TPB), P.NP);
         for (int wp = 0; wp < p->warps; ++wp) {
             k_warp<<<gpx, TPB, 0, st>>>(pyr[s], plane, lw, lh, lp, P.F, state[0], state[1], eps ? sel : nullptr, cur,
