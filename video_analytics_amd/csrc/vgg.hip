@@ -128,14 +128,17 @@ __device__ __forceinline__ void brick_coords(int m, int lgTW, int lgTH, int& xl,
 }
 
 // BM = WM*MT*32 output pixels x BN = WN*NT*32 output channels per workgroup of WM*WN waves.
-template <int WM, int WN, int MT, int NT, bool POOL>
+// BK = channels per K step (16 or 32): a pixel's BK-channel run is BK*4 contiguous bytes, so BK = 32
+// reads whole 128-byte lines and halves the barriers per FLOP.
+template <int WM, int WN, int MT, int NT, bool POOL, int BK>
 __global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
 {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32, NTHR = WM * WN * 64;
-    constexpr int A_ROWS_PER_PASS = NTHR / 4, A_PASSES = BM / A_ROWS_PER_PASS, B_PASSES = BN / A_ROWS_PER_PASS;
+    constexpr int QPR = BK / 4, LDS = BK + 4;  // float4 per row; padded LDS row (conflict-free ds_read_b128)
+    constexpr int A_ROWS_PER_PASS = NTHR / QPR, A_PASSES = BM / A_ROWS_PER_PASS, B_PASSES = BN / A_ROWS_PER_PASS;
     static_assert(BM % A_ROWS_PER_PASS == 0 && BN % A_ROWS_PER_PASS == 0, "tile/thread mismatch");
-    __shared__ __attribute__((aligned(16))) float sA[2][BM * kLdsStride];
-    __shared__ __attribute__((aligned(16))) float sB[2][BN * kLdsStride];
+    __shared__ __attribute__((aligned(16))) float sA[2][BM * LDS];
+    __shared__ __attribute__((aligned(16))) float sB[2][BN * LDS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -150,8 +153,8 @@ __global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
     const int H = a.H, W = a.W, Cin = a.Cin;
     const int X0 = tile_x << a.lgTW, Y0 = tile_y << a.lgTH, B0 = tile_b * a.TB;
 
-    // loader role: float4 column q of rows (tid>>2) + 64*i
-    const int q = tid & 3, rowbase = tid >> 2;
+    // loader role: float4 column q of rows tid/QPR + A_ROWS_PER_PASS*i
+    const int q = tid % QPR, rowbase = tid / QPR;
     int ax[A_PASSES], ay[A_PASSES];
     long apix[A_PASSES];
     bool aok[A_PASSES];
@@ -177,12 +180,12 @@ __global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
-    const int cchunks = Cin / kBK;
+    const int cchunks = Cin / BK;
     const int T = 9 * cchunks;
     float4 ra[A_PASSES], rb[B_PASSES];
 
     auto gload = [&](int t) {
-        const int kp = t / cchunks, c0 = (t - kp * cchunks) * kBK;
+        const int kp = t / cchunks, c0 = (t - kp * cchunks) * BK;
         const int ky = kp / 3 - 1, kx = kp % 3 - 1;
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
@@ -197,10 +200,10 @@ __global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i)
-            *reinterpret_cast<float4*>(&sA[buf][(rowbase + A_ROWS_PER_PASS * i) * kLdsStride + 4 * q]) = ra[i];
+            *reinterpret_cast<float4*>(&sA[buf][(rowbase + A_ROWS_PER_PASS * i) * LDS + 4 * q]) = ra[i];
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i)
-            *reinterpret_cast<float4*>(&sB[buf][(rowbase + A_ROWS_PER_PASS * i) * kLdsStride + 4 * q]) = rb[i];
+            *reinterpret_cast<float4*>(&sB[buf][(rowbase + A_ROWS_PER_PASS * i) * LDS + 4 * q]) = rb[i];
     };
 
     gload(0);
@@ -211,14 +214,14 @@ __global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
         const int buf = t & 1;
         if (t + 1 < T) gload(t + 1);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < BK / 8; ++g) {
             float4 fa[MT], fb[NT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                fa[mt] = *reinterpret_cast<const float4*>(&sA[buf][((wm * MT + mt) * 32 + r31) * kLdsStride + 8 * g + 4 * hh]);
+                fa[mt] = *reinterpret_cast<const float4*>(&sA[buf][((wm * MT + mt) * 32 + r31) * LDS + 8 * g + 4 * hh]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                fb[nt] = *reinterpret_cast<const float4*>(&sB[buf][((wn * NT + nt) * 32 + r31) * kLdsStride + 8 * g + 4 * hh]);
+                fb[nt] = *reinterpret_cast<const float4*>(&sB[buf][((wn * NT + nt) * 32 + r31) * LDS + 8 * g + 4 * hh]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -454,16 +457,18 @@ int launch_conv(const ConvLayer& L, const float* in, float* out, int B, hipStrea
     a.tiles_x = va_cdiv(L.hw, 1 << a.lgTW);
     a.tiles_y = va_cdiv(L.hw, 1 << a.lgTH);
     const int tiles_b = va_cdiv(B, a.TB);
+    // BK = 32 (whole 128-byte lines per pixel, half the barriers) was measured 5 % SLOWER than BK = 16:
+    // its 72 KB of LDS per workgroup drops the occupancy from 3 to 2 workgroups per CU.
     if (L.cout % 128 == 0) {
         a.tiles_n = L.cout / 128;
         const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
-        if (L.pool) k_conv3x3_mfma<2, 2, 2, 2, true><<<grid, 256, 0, st>>>(a);
-        else k_conv3x3_mfma<2, 2, 2, 2, false><<<grid, 256, 0, st>>>(a);
+        if (L.pool) k_conv3x3_mfma<2, 2, 2, 2, true, 16><<<grid, 256, 0, st>>>(a);
+        else k_conv3x3_mfma<2, 2, 2, 2, false, 16><<<grid, 256, 0, st>>>(a);
     } else {
         a.tiles_n = L.cout / 64;
         const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
-        if (L.pool) k_conv3x3_mfma<2, 2, 2, 1, true><<<grid, 256, 0, st>>>(a);
-        else k_conv3x3_mfma<2, 2, 2, 1, false><<<grid, 256, 0, st>>>(a);
+        if (L.pool) k_conv3x3_mfma<2, 2, 2, 1, true, 16><<<grid, 256, 0, st>>>(a);
+        else k_conv3x3_mfma<2, 2, 2, 1, false, 16><<<grid, 256, 0, st>>>(a);
     }
     VA_LAUNCH_CHECK();
     return VA_OK;
