@@ -31,19 +31,19 @@ BYTES_PER_PX_WARP = 44.0
 BATCH = 32
 
 
-def pmc_traffic_per_launch(block_iters):
+def pmc_traffic_per_launch(block_iters, flow_streams):
     """HBM bytes per k_iter_tile launch from the committed rocprofv3 PMC passes (profiles/rNN/
     pmc_hbm_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command;
     FETCH_SIZE doubled per the gfx950 rule of MI355X_MICROARCH.md, verified on this kernel's known
     load count in profiles/README.md).  PMC cannot be collected inside a normal run: this reports the
-    profiled figure for the same configuration, or None if no profile matches."""
+    profiled figure for the same configuration, or None if no profile matches it."""
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm_summary.json")))
     if not cands:
         return None
     try:
         d = json.load(open(cands[-1]))
-        if int(d.get("block_iters", 12)) != (block_iters or 12):
+        if int(d.get("block_iters", -1)) != block_iters or int(d.get("flow_streams", -1)) != flow_streams:
             return None
         f = sum(v["sum_KB"] for k, v in d["FETCH_SIZE"].items() if k.startswith("k_iter"))
         w = sum(v["sum_KB"] for k, v in d["WRITE_SIZE"].items() if k.startswith("k_iter"))
@@ -169,7 +169,7 @@ def main():
             alg_bytes = BYTES_PER_PX_ITER * prof["px_iters"]
             busy_ms = prof["union_ms"] if prof["union_ms"] > 0 else prof["ms"]
             ach = alg_bytes / (busy_ms * 1e-3) / 1e9
-            traffic = pmc_traffic_per_launch(args.block_iters) if args.flow_streams == 1 else None
+            traffic = pmc_traffic_per_launch(args.block_iters, args.flow_streams)
             roof = dict(bound="hbm", kernel="k_iter_tile (TV-L1 inner iterations)", achieved=ach, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic,
                         launches=int(prof["launches"]), avg_launch_us=prof["ms"] * 1e3 / prof["launches"],
