@@ -131,27 +131,31 @@ def synth_clips(n_clips, seed=0, H=224, W=224, n_gray=11, first_clip=0):
     Clip c of a call with ``first_clip=k`` equals clip c+k of a call with ``first_clip=0``.
     """
     M = 24  # texture margin so that moved samples stay inside
-    rgbs, grays, flows = [], [], []
+    n = n_clips
+    Ht, Wt = H + 2 * M, W + 2 * M
     yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
-    for c in range(first_clip, first_clip + n_clips):
-        u = torch.from_numpy(hash_uniform(seed, 3 * c, 3 * H * W).reshape(1, 3, H, W))
-        box = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(u, (1, 1, 1, 1), mode="reflect"), 3, stride=1)
-        rgbs.append((box[0] * 255.0).round().clamp(0, 255).to(torch.uint8))
-        Ht, Wt = H + 2 * M, W + 2 * M
-        t = torch.from_numpy(hash_uniform(seed, 3 * c + 1, Ht * Wt).reshape(1, 1, Ht, Wt))
-        t = _blur(t, 2.0)
-        t = (t - t.min()) / (t.max() - t.min()) * 255.0
-        ph = hash_uniform(seed, 3 * c + 2, 4)
-        amp = 1.0 + 2.0 * float(ph[0])
-        dx = 1.5 + amp * torch.sin(2 * math.pi * (yy / H) + 6.2831853 * float(ph[1]))
-        dy = -0.75 + amp * torch.cos(2 * math.pi * (xx / W) + 6.2831853 * float(ph[2]))
-        frames = []
-        for k in range(n_gray):
-            sx = xx + M - k * dx
-            sy = yy + M - k * dy
-            grid = torch.stack([(sx + 0.5) / Wt * 2 - 1, (sy + 0.5) / Ht * 2 - 1], dim=-1).unsqueeze(0)
-            f = torch.nn.functional.grid_sample(t, grid, mode="bilinear", padding_mode="border", align_corners=False)
-            frames.append(f[0, 0].round().clamp(0, 255).to(torch.uint8))
-        grays.append(torch.stack(frames))
-        flows.append(torch.stack([dx, dy]))
-    return torch.stack(rgbs), torch.stack(grays), torch.stack(flows)
+    u = torch.empty((n, 3, H, W), dtype=torch.float32)
+    t = torch.empty((n, 1, Ht, Wt), dtype=torch.float32)
+    ph = np.empty((n, 4), dtype=np.float32)
+    for i, c in enumerate(range(first_clip, first_clip + n)):
+        u[i] = torch.from_numpy(hash_uniform(seed, 3 * c, 3 * H * W).reshape(3, H, W))
+        t[i, 0] = torch.from_numpy(hash_uniform(seed, 3 * c + 1, Ht * Wt).reshape(Ht, Wt))
+        ph[i] = hash_uniform(seed, 3 * c + 2, 4)
+    box = torch.cat([torch.nn.functional.avg_pool2d(torch.nn.functional.pad(u[i:i + 1], (1, 1, 1, 1), mode="reflect"), 3, stride=1)
+                     for i in range(n)], dim=0)
+    rgb = (box * 255.0).round().clamp(0, 255).to(torch.uint8)
+    t = torch.cat([_blur(t[i:i + 1], 2.0) for i in range(n)], dim=0)  # per clip: conv2d is not batch-invariant
+    tmin = t.amin(dim=(2, 3), keepdim=True)
+    tmax = t.amax(dim=(2, 3), keepdim=True)
+    t = (t - tmin) / (tmax - tmin) * 255.0
+    amp = torch.from_numpy(1.0 + 2.0 * ph[:, 0]).view(n, 1, 1)
+    dx = 1.5 + amp * torch.sin(2 * math.pi * (yy / H).unsqueeze(0) + 6.2831853 * torch.from_numpy(ph[:, 1]).view(n, 1, 1))
+    dy = -0.75 + amp * torch.cos(2 * math.pi * (xx / W).unsqueeze(0) + 6.2831853 * torch.from_numpy(ph[:, 2]).view(n, 1, 1))
+    gray = torch.empty((n, n_gray, H, W), dtype=torch.uint8)
+    for k in range(n_gray):
+        sx = xx.unsqueeze(0) + M - k * dx
+        sy = yy.unsqueeze(0) + M - k * dy
+        grid = torch.stack([(sx + 0.5) / Wt * 2 - 1, (sy + 0.5) / Ht * 2 - 1], dim=-1)
+        f = torch.nn.functional.grid_sample(t, grid, mode="bilinear", padding_mode="border", align_corners=False)
+        gray[:, k] = f[:, 0].round().clamp(0, 255).to(torch.uint8)
+    return rgb, gray, torch.stack([dx, dy], dim=1)
