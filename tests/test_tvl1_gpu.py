@@ -52,6 +52,26 @@ def test_block_depth_and_remainders_bit_exact(oracle_tvl1, block_iters, iters):
     assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("H,W", [(16, 16), (17, 19), (33, 130), (65, 257)])
+def test_minimum_and_ragged_sizes_bit_exact(oracle_tvl1, H, W):
+    # the smallest accepted frame (16x16: a single pyramid level) and widths/heights that are not
+    # multiples of the 4-pixel runs or of the tile sizes (one column / row past a tile edge)
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    gray = (torch.rand(2, 2, H, W, generator=g) * 255).to(torch.uint8)
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=25, warps=2)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.02, iters=40, warps=2)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
+def test_many_short_sequences_bit_exact(oracle_tvl1):
+    # 40 sequences x 2 frames = 40 pairs of different content in one call (pair/frame index arithmetic)
+    g = torch.Generator().manual_seed(5)
+    gray = (torch.rand(40, 2, 24, 40, generator=g) * 255).to(torch.uint8)
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=10, warps=1, nscales=2)
+    assert np.array_equal(out, ref)
+
+
 def test_full_schedule_224_bit_exact(oracle_tvl1):
     # the benchmark's exact schedule: 5 scales x 5 warps x 300 iterations, one clip's first 2 pairs
     gray = _frames(1, 3, 224, 224, seed=0)
