@@ -10,6 +10,7 @@
   * vgg_small.npz    class scores / descriptors / per-layer fp64 checksums of the torch-CPU oracle
                      (oracle/vgg_oracle.py) for both streams on 4 synthetic clips with the synthetic
                      weights of video_analytics_amd/synth.py (seeds 1 and 2).
+  * reference_parameters.json  the 43 config constants of Sheet03/parameters.py (names + values).
   * demoTest.txt / demoTrain.txt are the reference's own video lists (data fixtures, copied
     verbatim from /root/reference/Sheet03/).
 """
@@ -74,7 +75,25 @@ def vgg():
     np.savez_compressed(os.path.join(HERE, "vgg_small.npz"), **res)
 
 
+def reference_parameters():
+    """Names and values of the reference's config constants (Sheet03/parameters.py imports cleanly under
+    Python 3: SURVEY.md section 8c) -> reference_parameters.json.  Data, not source."""
+    import importlib.util
+    import json
+    ref = "/root/reference/Sheet03/parameters.py"
+    if not os.path.exists(ref):
+        print("reference not mounted: reference_parameters.json left as committed")
+        return
+    spec = importlib.util.spec_from_file_location("ref_parameters", ref)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    vals = {n: getattr(mod, n) for n in dir(mod) if n.isupper()}
+    json.dump(vals, open(os.path.join(HERE, "reference_parameters.json"), "w"), indent=1, sort_keys=True)
+    print("reference parameters:", len(vals), "constants")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    reference_parameters()
     tvl1()
     vgg()

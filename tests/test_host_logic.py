@@ -24,6 +24,20 @@ def test_parameters_match_reference_values():
     assert parameters.COLOR_JITTERS == [0, 0, 0, 0] and parameters.CROP_SIZE_TF == 224
 
 
+def test_every_reference_constant_is_kept():
+    import json
+    ref = json.load(open(os.path.join(GOLD, "reference_parameters.json")))
+    assert len(ref) == 43
+    site_specific = {"DATA_DIR", "FLOW_DATA_DIR", "FRAMES_DIR_TRAIN", "FRAMES_DIR_TEST", "VIDEOLIST_TRAIN", "VIDEOLIST_TEST",
+                     "ACTIONLABEL_FILE", "CHECKPOINT_DIR"}  # absolute paths of the authors' machine (:26-33)
+    for name, value in ref.items():
+        assert hasattr(parameters, name), name
+        if name in site_specific:
+            assert os.path.basename(getattr(parameters, name).rstrip("/")) == os.path.basename(value.rstrip("/")), name
+        else:
+            assert getattr(parameters, name) == value, name
+
+
 def test_videoinfo_known_answers_from_the_reference_lists():
     test_lines = open(os.path.join(GOLD, "demoTest.txt")).readlines()
     train_lines = open(os.path.join(GOLD, "demoTrain.txt")).readlines()
