@@ -96,6 +96,8 @@ def main():
                     help="exact: bit-identical to the CPU oracle; fast: 1-ulp hardware sqrt/rcp (tolerance-tested)")
     ap.add_argument("--flow-streams", type=int, default=2,
                     help="split the batch's TV-L1 work over this many HIP streams (their tile launches overlap)")
+    ap.add_argument("--cnn-dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: exact fp32 MFMA (headline, parity); bf16: BASELINE config 5 throughput mode")
     ap.add_argument("--cpu-clips", type=int, default=2, help="clips in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-flow", action="store_true", help="CNN only on precomputed flow volumes (not the headline metric)")
     args = ap.parse_args()
@@ -120,7 +122,8 @@ def main():
 
     tv_kw = dict(epsilon=0.0, iters=300, warps=5, nscales=5)
     params = _ffi.default_tvl1_params(block_iters=args.block_iters, fast_math=int(args.tvl1_math == "fast"), **tv_kw)
-    pipe = pipeline.TwoStreamPipeline(device=local_rank, tvl1_params=params, flow_streams=args.flow_streams)
+    pipe = pipeline.TwoStreamPipeline(device=local_rank, tvl1_params=params, flow_streams=args.flow_streams,
+                                      cnn_dtype=args.cnn_dtype)
     # distinct clips per rank: clip index = rank*BATCH + i
     rgb, gray, _ = synth.synth_clips(BATCH, seed=0, first_clip=rank * BATCH)
     rgb, gray = rgb.to(dev), gray.to(dev)
@@ -182,7 +185,7 @@ def main():
             "metric": "clips/sec (224x224, RGB+10-flow two-stream)",
             "value": value, "unit": "clips/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed / max(K, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.cnn_dtype == "f32" else "bf16 (CNN) / f32 (TV-L1)", "data": "synthetic",
             "config": {"workload": "two-stream 224x224, 10-frame TV-L1 flow stack (5 scales x 5 warps x 300 its, fixed), "
                                    "VGG-16 spatial+temporal, batch=32 per GPU" + (" [CNN only: --no-flow]" if args.no_flow else ""),
                        "global_batch": world * BATCH, "block_iters": args.block_iters, "tvl1_math": args.tvl1_math, "flow_streams": args.flow_streams, "parallelism": "clips sharded x%d" % world,

@@ -65,7 +65,9 @@ void va_ctx_destroy(va_ctx* ctx);
  * c*49 + h*7 + w (Sheet03/spatialModel.py:213); fc_b[4]: f32 [out].
  * c_in is 3 (spatial) or 2L (temporal, 20).  in_mean/in_std: HOST arrays of c_in floats used
  * only when va_vgg16_forward is given u8 input (ToTensor+Normalize, Sheet03/utils.py:148-150);
- * may be NULL.  dtype: VA_DTYPE_F32 (fp32 in, fp32 MFMA accumulate).
+ * may be NULL.  dtype: VA_DTYPE_F32 (fp32 in, fp32 MFMA accumulate: the parity configuration) or
+ * VA_DTYPE_BF16 (bf16 activations and conv weights on the bf16 MFMA, fp32 accumulate, fp32 classifier:
+ * the throughput configuration of BASELINE config 5; class scores deviate at the 1e-2 level).
  * The call synchronises `stream` before returning (the source tensors may be freed).
  */
 int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_dim, int dtype,

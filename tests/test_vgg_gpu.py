@@ -96,6 +96,27 @@ def test_batch_40_crosses_fc_row_tile(weights3):
     m.close()
 
 
+def test_bf16_stream_tracks_the_fp32_stream(weights3):
+    """BASELINE config 5 (bf16 conv stack, fp32 accumulate/classifier): not a parity configuration -- the
+    test states its deviation from the fp32 oracle: relative error of the class scores below 3e-2 of their
+    range, identical arg-max on these inputs, and batch-composition independence."""
+    from oracle import vgg_oracle
+    from video_analytics_amd import vgg
+    w = weights3
+    x = _inputs(5, 3, seed=5)
+    _, desc_r, log_r = vgg_oracle.forward(x, w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"])
+    m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256, dtype="bf16")
+    feat, desc, logits = m.forward(x.cuda(), want_feat=True)
+    scale = float(log_r.abs().max())
+    err = float((logits.cpu() - log_r).abs().max())
+    assert err / scale < 3e-2, (err, scale)
+    assert err > 1e-4  # it really is the bf16 path
+    assert torch.equal(logits.cpu().argmax(1), log_r.argmax(1))
+    _, _, one = m.forward(x[3:4].cuda())
+    assert torch.equal(one[0], logits[3])
+    m.close()
+
+
 def test_validate_batch_matches_oracle():
     from oracle import vgg_oracle
     from video_analytics_amd import vgg

@@ -4,11 +4,12 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from video_analytics_amd import pipeline, synth
-pipe = pipeline.TwoStreamPipeline(device=0)
+dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
+pipe = pipeline.TwoStreamPipeline(device=0, cnn_dtype=dtype)
 rgb, gray, _ = synth.synth_clips(32, seed=0)
 rgb = rgb.cuda(); stack = torch.randn(32, 20, 224, 224, device='cuda')
 for _ in range(2): pipe.run_batch(rgb, flow_stack=stack)
 torch.cuda.synchronize(); t=time.perf_counter()
 for _ in range(5): out = pipe.run_batch(rgb, flow_stack=stack)
 torch.cuda.synchronize(); dt=(time.perf_counter()-t)/5
-print("CNN both streams B=32: %.2f ms  -> %.1f TFLOP/s" % (dt*1e3, 32*62.852e9/dt/1e12))
+print("CNN (%s) both streams B=32: %.2f ms  -> %.1f TFLOP/s" % (dtype, dt*1e3, 32*62.852e9/dt/1e12))

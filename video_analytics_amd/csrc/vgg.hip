@@ -271,6 +271,200 @@ __global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
     }
 }
 
+// ---------------------------------------------------------------- bf16 conv3x3 (BASELINE config 5) ------
+//
+// Same implicit GEMM and the same pooling-friendly pixel brick, with bf16 activations/weights and fp32
+// accumulation on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  K step = 64 channels: a pixel's
+// chunk is one 128-byte line; LDS rows are padded to 144 B so that the 16-byte fragment reads of the 32
+// rows of a half-wave fall on distinct bank groups.  The first layer's input channels are zero-padded
+// to 64.  Results deviate from the fp32 path at the bf16 level (~1e-2 relative on class scores): this is
+// the throughput configuration, not the parity configuration (DESIGN.md "Numerics of the CNN").
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kBfBK = 64;      // channels per K step
+constexpr int kBfLds = 72;     // bf16 elements per LDS row (144 B)
+
+// x NCHW (f32 or u8 + ToTensor/Normalize) -> NHWC bf16 with C padded to cpad
+template <typename T>
+__global__ void k_nchw_to_nhwc_bf16(const T* __restrict__ x, __bf16* __restrict__ out, int B, int C, int HW, int cpad,
+                                    const float* __restrict__ mean, const float* __restrict__ stdv)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * HW) return;
+    const int b = (int)(idx / HW), p = (int)(idx - (size_t)b * HW);
+    __bf16* o = out + idx * cpad;
+    for (int c = 0; c < cpad; ++c) {
+        float v = 0.0f;
+        if (c < C) {
+            const T raw = x[((size_t)b * C + c) * HW + p];
+            if constexpr (sizeof(T) == 1) v = ((float)raw / 255.0f - mean[c]) / stdv[c];
+            else v = (float)raw;
+        }
+        o[c] = (__bf16)v;
+    }
+}
+
+// OIHW f32 [Cout][Cin][3][3] -> bf16 [Cout][9][cpad]
+__global__ void k_pack_conv_w_bf16(const float* __restrict__ w, __bf16* __restrict__ wp, int Cout, int Cin, int cpad)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)Cout * 9 * cpad;
+    if (idx >= total) return;
+    const int ci = (int)(idx % cpad);
+    const int kp = (int)((idx / cpad) % 9);
+    const int n = (int)(idx / ((size_t)cpad * 9));
+    wp[idx] = (__bf16)(ci < Cin ? w[((size_t)n * Cin + ci) * 9 + kp] : 0.0f);
+}
+
+struct ConvArgsBf {
+    const __bf16* in;   // NHWC [B][H][W][Cin], Cin % 64 == 0
+    const __bf16* wp;   // [Cout][9*Cin]
+    const float* bias;  // [Cout]
+    void* out;          // NHWC bf16 (or f32 when OUT_F32), pooled when POOL
+    int B, H, W, Cin, Cout;
+    int lgTW, lgTH, TB;
+    int tiles_x, tiles_y, tiles_n;
+};
+
+// 128 pixels x (NT*64) channels per workgroup of 4 waves (2 x 2), wave tile 64 x (NT*32).
+template <int NT, bool POOL, bool OUT_F32>
+__global__ void __launch_bounds__(256) k_conv3x3_mfma_bf16(ConvArgsBf a)
+{
+    constexpr int BM = 128, BN = NT * 64, MT = 2;
+    constexpr int ROWS_PER_PASS = 32, A_PASSES = BM / ROWS_PER_PASS, B_PASSES = BN / ROWS_PER_PASS;
+    __shared__ __attribute__((aligned(16))) __bf16 sA[2][BM * kBfLds];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[2][BN * kBfLds];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bid = blockIdx.x;
+    const int n_tile = bid % a.tiles_n;
+    bid /= a.tiles_n;
+    const int tile_x = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int tile_y = bid % a.tiles_y;
+    const int tile_b = bid / a.tiles_y;
+    const int n0 = n_tile * BN;
+    const int H = a.H, W = a.W, Cin = a.Cin;
+    const int X0 = tile_x << a.lgTW, Y0 = tile_y << a.lgTH, B0 = tile_b * a.TB;
+
+    // loader role: 16-byte chunk q (8 channels) of rows (tid>>3) + 32*i
+    const int q = tid & 7, rowbase = tid >> 3;
+    int ax[A_PASSES], ay[A_PASSES];
+    long apix[A_PASSES];
+    bool aok[A_PASSES];
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        int xl, yl, bl;
+        brick_coords(rowbase + ROWS_PER_PASS * i, a.lgTW, a.lgTH, xl, yl, bl);
+        ax[i] = X0 + xl;
+        ay[i] = Y0 + yl;
+        const int b = B0 + bl;
+        aok[i] = b < a.B && ax[i] < W && ay[i] < H;
+        apix[i] = (((long)b * H + ay[i]) * W + ax[i]) * Cin + 8 * q;
+    }
+    const __bf16* wrow[B_PASSES];
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) wrow[i] = a.wp + (size_t)(n0 + rowbase + ROWS_PER_PASS * i) * 9 * Cin + 8 * q;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    const int cchunks = Cin / kBfBK;
+    const int T = 9 * cchunks;
+    uint4 ra[A_PASSES], rb[B_PASSES];
+    auto gload = [&](int t) {
+        const int kp = t / cchunks, c0 = (t - kp * cchunks) * kBfBK;
+        const int ky = kp / 3 - 1, kx = kp % 3 - 1;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            const int yy = ay[i] + ky, xx = ax[i] + kx;
+            const bool ok = aok[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            ra[i] = ok ? *reinterpret_cast<const uint4*>(a.in + apix[i] + ((long)ky * W + kx) * Cin + c0) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (size_t)kp * Cin + c0);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i)
+            *reinterpret_cast<uint4*>(&sA[buf][(rowbase + ROWS_PER_PASS * i) * kBfLds + 8 * q]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i)
+            *reinterpret_cast<uint4*>(&sB[buf][(rowbase + ROWS_PER_PASS * i) * kBfLds + 8 * q]) = rb[i];
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int r31 = lane & 31, hh = lane >> 5;
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T) gload(t + 1);
+#pragma unroll
+        for (int ks = 0; ks < kBfBK / 16; ++ks) {
+            bf16x8 fa[MT], fb[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                fa[mt] = *reinterpret_cast<const bf16x8*>(&sA[buf][((wm * MT + mt) * 32 + r31) * kBfLds + 16 * ks + 8 * hh]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                fb[nt] = *reinterpret_cast<const bf16x8*>(&sB[buf][((wn * NT + nt) * 32 + r31) * kBfLds + 16 * ks + 8 * hh]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+        }
+        if (t + 1 < T) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: bias + ReLU (+ 2x2 max-pool over the 4 registers reg&3 of a lane), fp32 math, bf16/f32 store
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + (wn * NT + nt) * 32 + r31;
+        const float bias = a.bias[n];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int mbase = (wm * MT + mt) * 32 + 8 * g4 + 4 * hh;
+                int xl, yl, bl;
+                brick_coords(mbase, a.lgTW, a.lgTH, xl, yl, bl);
+                const int x = X0 + xl, y = Y0 + yl, b = B0 + bl;
+                if (b >= a.B) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[mt][nt][4 * g4 + j] + bias, 0.0f);
+                if constexpr (POOL) {
+                    if (x < W && y < H) {
+                        const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        const size_t o = ((((size_t)b * (H >> 1)) + (y >> 1)) * (W >> 1) + (x >> 1)) * a.Cout + n;
+                        if constexpr (OUT_F32) ((float*)a.out)[o] = mx;
+                        else ((__bf16*)a.out)[o] = (__bf16)mx;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int xx = x + (j & 1), yy = y + (j >> 1);
+                        if (xx < W && yy < H) {
+                            const size_t o = (((size_t)b * H + yy) * W + xx) * a.Cout + n;
+                            if constexpr (OUT_F32) ((float*)a.out)[o] = v[j];
+                            else ((__bf16*)a.out)[o] = (__bf16)v[j];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- FC split-K GEMM --------------
 
 struct FcArgs {
@@ -401,7 +595,8 @@ __global__ void k_validate_batch(const float* __restrict__ logits, const long lo
 struct ConvLayer {
     int cin, cin_pad, cout, hw;  // hw = input height = width
     bool pool;
-    float* wp;
+    float* wp;      // f32 [Cout][9*cin_pad]  (VA_DTYPE_F32)
+    __bf16* wp_bf;  // bf16 [Cout][9*cin_pad] (VA_DTYPE_BF16)
     float* bias;
 };
 
@@ -412,7 +607,7 @@ constexpr bool kConvPool[13] = {false, true, false, true, false, false, true, fa
 
 struct va_vgg16 {
     va_ctx* ctx;
-    int c_in, c_in_pad, n_classes, desc_dim;
+    int c_in, c_in_pad, n_classes, desc_dim, dtype;
     ConvLayer conv[13];
     float* fcw[4];
     float* fcb[4];
@@ -469,6 +664,41 @@ int launch_conv(const ConvLayer& L, const float* in, float* out, int B, hipStrea
         const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
         if (L.pool) k_conv3x3_mfma<2, 2, 2, 1, true, 16><<<grid, 256, 0, st>>>(a);
         else k_conv3x3_mfma<2, 2, 2, 1, false, 16><<<grid, 256, 0, st>>>(a);
+    }
+    VA_LAUNCH_CHECK();
+    return VA_OK;
+}
+
+int launch_conv_bf16(const ConvLayer& L, const __bf16* in, void* out, bool out_f32, int B, hipStream_t st)
+{
+    ConvArgsBf a{};
+    a.in = in;
+    a.wp = L.wp_bf;
+    a.bias = L.bias;
+    a.out = out;
+    a.B = B;
+    a.H = a.W = L.hw;
+    a.Cin = L.cin_pad;
+    a.Cout = L.cout;
+    pick_brick(L.hw, L.hw, B, a.lgTW, a.lgTH, a.TB);
+    a.tiles_x = va_cdiv(L.hw, 1 << a.lgTW);
+    a.tiles_y = va_cdiv(L.hw, 1 << a.lgTH);
+    const int tiles_b = va_cdiv(B, a.TB);
+    if (L.cout % 128 == 0) {
+        a.tiles_n = L.cout / 128;
+        const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
+        if (out_f32) {  // only the last layer (pooled)
+            k_conv3x3_mfma_bf16<2, true, true><<<grid, 256, 0, st>>>(a);
+        } else if (L.pool) {
+            k_conv3x3_mfma_bf16<2, true, false><<<grid, 256, 0, st>>>(a);
+        } else {
+            k_conv3x3_mfma_bf16<2, false, false><<<grid, 256, 0, st>>>(a);
+        }
+    } else {
+        a.tiles_n = L.cout / 64;
+        const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
+        if (L.pool) k_conv3x3_mfma_bf16<1, true, false><<<grid, 256, 0, st>>>(a);
+        else k_conv3x3_mfma_bf16<1, false, false><<<grid, 256, 0, st>>>(a);
     }
     VA_LAUNCH_CHECK();
     return VA_OK;
@@ -567,7 +797,7 @@ extern "C" int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_di
     VA_CHECK_ARG(c_in >= 1 && c_in <= 64, "va_vgg16_create: c_in %d out of range [1,64]", c_in);
     VA_CHECK_ARG(n_classes >= 1 && n_classes <= 4096 && desc_dim >= 16 && desc_dim <= 4096 && desc_dim % 16 == 0,
                  "va_vgg16_create: n_classes %d / desc_dim %d unsupported (desc_dim must be a multiple of 16)", n_classes, desc_dim);
-    VA_CHECK_ARG(dtype == VA_DTYPE_F32, "va_vgg16_create: only VA_DTYPE_F32 is implemented");
+    VA_CHECK_ARG(dtype == VA_DTYPE_F32 || dtype == VA_DTYPE_BF16, "va_vgg16_create: dtype must be VA_DTYPE_F32 or VA_DTYPE_BF16");
     VA_CHECK_ARG(conv_w && conv_b && fc_w && fc_b, "va_vgg16_create: NULL weight tables");
     for (int i = 0; i < 13; ++i) VA_CHECK_ARG(conv_w[i] && conv_b[i], "va_vgg16_create: conv layer %d weight/bias is NULL", i);
     for (int i = 0; i < 4; ++i) VA_CHECK_ARG(fc_w[i] && fc_b[i], "va_vgg16_create: fc layer %d weight/bias is NULL", i);
@@ -576,7 +806,8 @@ extern "C" int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_di
     memset(m, 0, sizeof(*m));
     m->ctx = ctx;
     m->c_in = c_in;
-    m->c_in_pad = va_cdiv(c_in, 16) * 16;
+    m->dtype = dtype;
+    m->c_in_pad = dtype == VA_DTYPE_BF16 ? 64 : va_cdiv(c_in, 16) * 16;
     m->n_classes = n_classes;
     m->desc_dim = desc_dim;
     int hw = 224, cin = c_in, cin_pad = m->c_in_pad;
@@ -590,11 +821,14 @@ extern "C" int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_di
         L.hw = hw;
         L.pool = kConvPool[i];
         const size_t nw = (size_t)L.cout * 9 * L.cin_pad;
-        if (hipMalloc(&L.wp, nw * sizeof(float)) != hipSuccess || hipMalloc(&L.bias, L.cout * sizeof(float)) != hipSuccess) {
+        const bool bf = dtype == VA_DTYPE_BF16;
+        if ((bf ? hipMalloc(&L.wp_bf, nw * sizeof(__bf16)) : hipMalloc(&L.wp, nw * sizeof(float))) != hipSuccess ||
+            hipMalloc(&L.bias, L.cout * sizeof(float)) != hipSuccess) {
             va_set_error("va_vgg16_create: hipMalloc failed for conv layer %d", i);
             return fail(VA_ERR_HIP);
         }
-        k_pack_conv_w<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>((const float*)conv_w[i], L.wp, L.cout, L.cin, L.cin_pad);
+        if (bf) k_pack_conv_w_bf16<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>((const float*)conv_w[i], L.wp_bf, L.cout, L.cin, L.cin_pad);
+        else k_pack_conv_w<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>((const float*)conv_w[i], L.wp, L.cout, L.cin, L.cin_pad);
         if (hipMemcpyAsync(L.bias, conv_b[i], L.cout * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = VA_ERR_HIP;
         cin = cin_pad = L.cout;
         if (L.pool) hw /= 2;
@@ -636,6 +870,7 @@ extern "C" void va_vgg16_destroy(va_vgg16* m)
     if (!m) return;
     for (int i = 0; i < 13; ++i) {
         if (m->conv[i].wp) hipFree(m->conv[i].wp);
+        if (m->conv[i].wp_bf) hipFree(m->conv[i].wp_bf);
         if (m->conv[i].bias) hipFree(m->conv[i].bias);
     }
     for (int i = 0; i < 4; ++i) {
@@ -672,21 +907,32 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
     float* slab = (float*)(ws + wp.off_slab);
     float* fcbuf[2] = {(float*)(ws + wp.off_fc[0]), (float*)(ws + wp.off_fc[1])};
     const int B = batch, HW0 = 224 * 224;
-    {
-        const size_t n = (size_t)B * HW0;
-        const unsigned grid = (unsigned)((n + 255) / 256);
-        if (x_is_u8)
-            k_nchw_to_nhwc_pad<unsigned char><<<grid, 256, 0, st>>>((const unsigned char*)x, act[1], B, m->c_in, HW0, m->c_in_pad, m->in_mean, m->in_std);
-        else
-            k_nchw_to_nhwc_pad<float><<<grid, 256, 0, st>>>((const float*)x, act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
-        VA_LAUNCH_CHECK();
-    }
+    const size_t npix = (size_t)B * HW0;
+    const unsigned pgrid = (unsigned)((npix + 255) / 256);
     int cur = 1;
-    for (int i = 0; i < 13; ++i) {
-        if (int rc = launch_conv(m->conv[i], act[cur], act[cur ^ 1], B, st)) return rc;
-        cur ^= 1;
+    if (m->dtype == VA_DTYPE_BF16) {
+        // bf16 activations live in the same two ping-pong buffers (half their size is used)
+        if (x_is_u8)
+            k_nchw_to_nhwc_bf16<unsigned char><<<pgrid, 256, 0, st>>>((const unsigned char*)x, (__bf16*)act[1], B, m->c_in, HW0, m->c_in_pad, m->in_mean, m->in_std);
+        else
+            k_nchw_to_nhwc_bf16<float><<<pgrid, 256, 0, st>>>((const float*)x, (__bf16*)act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
+        VA_LAUNCH_CHECK();
+        for (int i = 0; i < 13; ++i) {
+            if (int rc = launch_conv_bf16(m->conv[i], (const __bf16*)act[cur], act[cur ^ 1], i == 12, B, st)) return rc;
+            cur ^= 1;
+        }
+    } else {
+        if (x_is_u8)
+            k_nchw_to_nhwc_pad<unsigned char><<<pgrid, 256, 0, st>>>((const unsigned char*)x, act[1], B, m->c_in, HW0, m->c_in_pad, m->in_mean, m->in_std);
+        else
+            k_nchw_to_nhwc_pad<float><<<pgrid, 256, 0, st>>>((const float*)x, act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
+        VA_LAUNCH_CHECK();
+        for (int i = 0; i < 13; ++i) {
+            if (int rc = launch_conv(m->conv[i], act[cur], act[cur ^ 1], B, st)) return rc;
+            cur ^= 1;
+        }
     }
-    const float* f = act[cur];  // NHWC [B][7][7][512]
+    const float* f = act[cur];  // NHWC f32 [B][7][7][512] (the last bf16 layer stores f32)
     if (feat) {
         const size_t n = (size_t)B * 512 * 49;
         k_nhwc_to_nchw<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(f, (float*)feat, B, 512, 49);

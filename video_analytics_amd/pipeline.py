@@ -25,7 +25,7 @@ def build_stream_weights(c_in, seed, device):
 
 class TwoStreamPipeline(object):
     def __init__(self, device=None, spatial_seed=1, temporal_seed=2, flow_count=VIDEO_INPUT_FLOW_COUNT,
-                 tvl1_params=None, weights=None, flow_streams=2):
+                 tvl1_params=None, weights=None, flow_streams=2, cnn_dtype="f32"):
         dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.device = dev
         self.L = flow_count
@@ -33,9 +33,10 @@ class TwoStreamPipeline(object):
             ws = weights[0] if weights else build_stream_weights(3, spatial_seed, dev)
             wt = weights[1] if weights else build_stream_weights(2 * flow_count, temporal_seed, dev)
             self.spatial = vgg.Vgg16Stream(ws["conv_w"], ws["conv_b"], ws["fc_w"], ws["fc_b"], NACTION_CLASSES,
-                                           VIDEO_DESCRIPTOR_DIM, NORM_MEANS_TF, NORM_STDS_TF, device=dev.index, ws_slot=1)
+                                           VIDEO_DESCRIPTOR_DIM, NORM_MEANS_TF, NORM_STDS_TF, device=dev.index, ws_slot=1,
+                                           dtype=cnn_dtype)
             self.temporal = vgg.Vgg16Stream(wt["conv_w"], wt["conv_b"], wt["fc_w"], wt["fc_b"], NACTION_CLASSES,
-                                            VIDEO_DESCRIPTOR_DIM, device=dev.index)
+                                            VIDEO_DESCRIPTOR_DIM, device=dev.index, dtype=cnn_dtype)
         self.tvl1_params = tvl1_params
         self.flow_streams = flow_streams
         # (running the spatial CNN beside TV-L1 on a third stream was measured slower: -5 %)

@@ -43,7 +43,12 @@ class Vgg16Stream(object):
     Linear(D,nClasses), weights packed once for the gfx950 kernels."""
 
     def __init__(self, conv_w, conv_b, fc_w, fc_b, n_classes, desc_dim, in_mean=None, in_std=None, device=None,
-                 ws_slot=0):
+                 ws_slot=0, dtype="f32"):
+        """``dtype``: "f32" (exact fp32 MFMA: the parity configuration) or "bf16" (bf16 conv stack with fp32
+        accumulation and fp32 classifier: BASELINE config 5, class scores deviate at the 1e-2 level)."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("Vgg16Stream: dtype must be 'f32' or 'bf16'")
+        self.dtype = dtype
         if len(conv_w) != 13 or len(conv_b) != 13 or len(fc_w) != 4 or len(fc_b) != 4:
             raise ValueError("Vgg16Stream: need 13 conv and 4 fc weight/bias tensors")
         dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -84,7 +89,8 @@ class Vgg16Stream(object):
             std = (ctypes.c_float * self.c_in)(*[float(v) for v in in_std])
         h = ctypes.c_void_p()
         with torch.cuda.device(dev):
-            _ffi.check(_ffi.lib().va_vgg16_create(_ffi.ctx(dev.index), self.c_in, self.n_classes, self.desc_dim, 0,
+            _ffi.check(_ffi.lib().va_vgg16_create(_ffi.ctx(dev.index), self.c_in, self.n_classes, self.desc_dim,
+                                                  1 if dtype == "bf16" else 0,
                                                   cw, cb, fw, fb, mean, std, _ffi.stream_ptr(), ctypes.byref(h)))
         self._h = h
         del keep
