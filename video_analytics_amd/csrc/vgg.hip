@@ -33,24 +33,31 @@ constexpr int kLdsStride = 20;  // floats per LDS row: 80 B keeps ds_read_b128 c
 
 // ---------------------------------------------------------------- layout / packing kernels ----
 
-// x NCHW (f32, or u8 with ToTensor+Normalize: Sheet03/utils.py:148-150) -> NHWC with C padded to cpad.
-template <typename T>
-__global__ void k_nchw_to_nhwc_pad(const T* __restrict__ x, float* __restrict__ out, int B, int C, int HW, int cpad,
-                                   const float* __restrict__ mean, const float* __restrict__ stdv)
+// x NCHW (f32, or u8 with ToTensor+Normalize: Sheet03/utils.py:148-150) -> NHWC (f32 or bf16) with C padded
+// to cpad <= 64.  One workgroup transposes 64 pixels x cpad channels through LDS: reads are coalesced along
+// the pixels of a channel plane, writes are one contiguous run of 64*cpad elements.
+template <typename TIN, typename TOUT>
+__global__ void __launch_bounds__(256) k_nchw_to_nhwc_pad(const TIN* __restrict__ x, TOUT* __restrict__ out, int B, int C,
+                                                           int HW, int cpad, const float* __restrict__ mean,
+                                                           const float* __restrict__ stdv)
 {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)B * HW) return;
-    const int b = (int)(idx / HW), p = (int)(idx - (size_t)b * HW);
-    float* o = out + idx * cpad;
-    for (int c = 0; c < cpad; ++c) {
+    __shared__ float tile[64][65];
+    const int tiles_per_img = (HW + 63) / 64;
+    const int b = blockIdx.x / tiles_per_img, p0 = (blockIdx.x - b * tiles_per_img) * 64;
+    const int t = threadIdx.x, p = t & 63;
+    for (int c = t >> 6; c < cpad; c += 4) {
         float v = 0.0f;
-        if (c < C) {
-            const T raw = x[((size_t)b * C + c) * HW + p];
-            if constexpr (sizeof(T) == 1) v = ((float)raw / 255.0f - mean[c]) / stdv[c];
+        if (c < C && p0 + p < HW) {
+            const TIN raw = x[((size_t)b * C + c) * HW + p0 + p];
+            if constexpr (sizeof(TIN) == 1) v = ((float)raw / 255.0f - mean[c]) / stdv[c];
             else v = (float)raw;
         }
-        o[c] = v;
+        tile[p][c] = v;
     }
+    __syncthreads();
+    const int npx = HW - p0 < 64 ? HW - p0 : 64;
+    TOUT* o = out + ((size_t)b * HW + p0) * cpad;
+    for (int i = t; i < npx * cpad; i += 256) o[i] = (TOUT)tile[i / cpad][i % cpad];
 }
 
 // OIHW [Cout][Cin][3][3] -> [Cout][9][cpad]
@@ -75,6 +82,17 @@ __global__ void k_pack_fc1(const float* __restrict__ w, float* __restrict__ wp, 
     const int p = (int)((idx / C) % HW);
     const size_t o = idx / ((size_t)C * HW);
     wp[idx] = w[(o * C + c) * HW + p];
+}
+
+// NCHW [B][C][HW] -> NHWC [B][HW][C]  (small tensors: the classifier's feature-map input)
+__global__ void k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * C * HW) return;
+    const int c = (int)(idx % C);
+    const int p = (int)((idx / C) % HW);
+    const size_t b = idx / ((size_t)HW * C);
+    out[idx] = in[(b * C + c) * HW + p];
 }
 
 // NHWC [B][HW][C] -> NCHW [B][C][HW]  (optional `feat` output)
@@ -283,26 +301,6 @@ __global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kBfBK = 64;      // channels per K step
 constexpr int kBfLds = 72;     // bf16 elements per LDS row (144 B)
-
-// x NCHW (f32 or u8 + ToTensor/Normalize) -> NHWC bf16 with C padded to cpad
-template <typename T>
-__global__ void k_nchw_to_nhwc_bf16(const T* __restrict__ x, __bf16* __restrict__ out, int B, int C, int HW, int cpad,
-                                    const float* __restrict__ mean, const float* __restrict__ stdv)
-{
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)B * HW) return;
-    const int b = (int)(idx / HW), p = (int)(idx - (size_t)b * HW);
-    __bf16* o = out + idx * cpad;
-    for (int c = 0; c < cpad; ++c) {
-        float v = 0.0f;
-        if (c < C) {
-            const T raw = x[((size_t)b * C + c) * HW + p];
-            if constexpr (sizeof(T) == 1) v = ((float)raw / 255.0f - mean[c]) / stdv[c];
-            else v = (float)raw;
-        }
-        o[c] = (__bf16)v;
-    }
-}
 
 // OIHW f32 [Cout][Cin][3][3] -> bf16 [Cout][9][cpad]
 __global__ void k_pack_conv_w_bf16(const float* __restrict__ w, __bf16* __restrict__ wp, int Cout, int Cin, int cpad)
@@ -907,15 +905,14 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
     float* slab = (float*)(ws + wp.off_slab);
     float* fcbuf[2] = {(float*)(ws + wp.off_fc[0]), (float*)(ws + wp.off_fc[1])};
     const int B = batch, HW0 = 224 * 224;
-    const size_t npix = (size_t)B * HW0;
-    const unsigned pgrid = (unsigned)((npix + 255) / 256);
+    const unsigned pgrid = (unsigned)(B * ((HW0 + 63) / 64));  // one workgroup per 64 pixels
     int cur = 1;
     if (m->dtype == VA_DTYPE_BF16) {
         // bf16 activations live in the same two ping-pong buffers (half their size is used)
         if (x_is_u8)
-            k_nchw_to_nhwc_bf16<unsigned char><<<pgrid, 256, 0, st>>>((const unsigned char*)x, (__bf16*)act[1], B, m->c_in, HW0, m->c_in_pad, m->in_mean, m->in_std);
+            k_nchw_to_nhwc_pad<unsigned char, __bf16><<<pgrid, 256, 0, st>>>((const unsigned char*)x, (__bf16*)act[1], B, m->c_in, HW0, m->c_in_pad, m->in_mean, m->in_std);
         else
-            k_nchw_to_nhwc_bf16<float><<<pgrid, 256, 0, st>>>((const float*)x, (__bf16*)act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
+            k_nchw_to_nhwc_pad<float, __bf16><<<pgrid, 256, 0, st>>>((const float*)x, (__bf16*)act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
         VA_LAUNCH_CHECK();
         for (int i = 0; i < 13; ++i) {
             if (int rc = launch_conv_bf16(m->conv[i], (const __bf16*)act[cur], act[cur ^ 1], i == 12, B, st)) return rc;
@@ -923,9 +920,9 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
         }
     } else {
         if (x_is_u8)
-            k_nchw_to_nhwc_pad<unsigned char><<<pgrid, 256, 0, st>>>((const unsigned char*)x, act[1], B, m->c_in, HW0, m->c_in_pad, m->in_mean, m->in_std);
+            k_nchw_to_nhwc_pad<unsigned char, float><<<pgrid, 256, 0, st>>>((const unsigned char*)x, act[1], B, m->c_in, HW0, m->c_in_pad, m->in_mean, m->in_std);
         else
-            k_nchw_to_nhwc_pad<float><<<pgrid, 256, 0, st>>>((const float*)x, act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
+            k_nchw_to_nhwc_pad<float, float><<<pgrid, 256, 0, st>>>((const float*)x, act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
         VA_LAUNCH_CHECK();
         for (int i = 0; i < 13; ++i) {
             if (int rc = launch_conv(m->conv[i], act[cur], act[cur ^ 1], B, st)) return rc;
@@ -959,8 +956,8 @@ extern "C" int va_vgg16_classify(va_vgg16* m, const void* feat, int batch, void*
     float* nhwc = (float*)(ws + wp.off_act[0]);
     float* slab = (float*)(ws + wp.off_slab);
     float* fcbuf[2] = {(float*)(ws + wp.off_fc[0]), (float*)(ws + wp.off_fc[1])};
-    const size_t n = (size_t)batch * 49;
-    k_nchw_to_nhwc_pad<float><<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const float*)feat, nhwc, batch, 512, 49, 512, nullptr, nullptr);
+    const size_t n = (size_t)batch * 49 * 512;
+    k_nchw_to_nhwc<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const float*)feat, nhwc, batch, 512, 49);
     VA_LAUNCH_CHECK();
     if (desc || logits) return run_classifier(m, nhwc, batch, desc, logits, slab, fcbuf, st);
     return VA_OK;
