@@ -1,0 +1,17 @@
+"""Time of the TV-L1 solve at each pyramid-level size of the 224x224 benchmark on its own (single level,
+5 warps x 300 iterations, 320 pairs on two streams), for the tile-shape / block-depth cost model.
+Run on the GPU box: python tools/bench_tvl1_levels.py [block_iters ...]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from video_analytics_amd import _ffi, flow as vflow
+
+Ks = [int(a) for a in sys.argv[1:]] or [0]
+torch.manual_seed(0)
+for n in (224, 179, 143, 114, 91):
+    fr = (torch.rand(320, 2, n, n, device="cuda") * 255).to(torch.uint8)
+    for K in Ks:
+        p = _ffi.default_tvl1_params(epsilon=0.0, nscales=1, block_iters=K)
+        vflow.tvl1_flow_concurrent(fr, p, 2); torch.cuda.synchronize()
+        t = time.perf_counter(); vflow.tvl1_flow_concurrent(fr, p, 2); torch.cuda.synchronize(); dt = time.perf_counter() - t
+        print("%3dx%-3d block_iters=%2d: %.1f ms  (%.0f Gpx-it/s)" % (n, n, K, dt * 1e3, 320 * n * n * 1500 / dt / 1e9))

@@ -317,13 +317,15 @@ __device__ __forceinline__ void store_row(float* __restrict__ row, int x0, int p
 // v_pk_mul_f32 / v_pk_add_f32 (two pixels per VALU instruction: a wave64 VALU instruction occupies
 // its SIMD for 4 cycles on gfx950 whether it is packed or not -- measured, profiles/README.md).
 //
-// LX = lanes of a wave along x (64, or 32: the wave is folded into two row groups so that a 128-pixel
-// wide tile still uses 16-byte accesses); NG = NW*64/LX row groups of C rows each.
+// LX = lanes of a wave along x.  A wave is folded into GPW = 64/LX row groups of LX lanes (LX = 64:
+// 256x32 tile; 32: 128x64; 21: 84x96, lane 63 idle; 16: 64x128), so that narrow pyramid levels get
+// tall tiles; NG = NW*GPW row groups of C rows each.
 template <int RP, int C, int NW, int LX, bool EPS, bool FAST>
 __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
 {
-    constexpr int R = 2 * RP, TW = LX * R, NG = NW * (64 / LX), TH = NG * C;
-    __shared__ __attribute__((aligned(16))) float sP12[NG][TW], sP22[NG][TW], sU1[NG][TW], sU2[NG][TW];
+    constexpr int R = 2 * RP, TW = LX * R, GPW = 64 / LX, NG = NW * GPW, TH = NG * C;
+    // row NG of the exchange arrays is a dummy for idle lanes (64 % LX != 0)
+    __shared__ __attribute__((aligned(16))) float sP12[NG + 1][TW], sP22[NG + 1][TW], sU1[NG + 1][TW], sU2[NG + 1][TW];
     __shared__ unsigned long long sErr;
 
     const int pair = blockIdx.y;
@@ -336,15 +338,17 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
         if (blockIdx.x == 0 && threadIdx.x == 0) a.sel[pair] = inbuf ^ 1;
         if (threadIdx.x == 0) sErr = 0ull;
     }
-    const int lane = (threadIdx.x & 63) & (LX - 1);                       // position along x
-    const int wave = (threadIdx.x >> 6) * (64 / LX) + (threadIdx.x & 63) / LX;  // row group
+    const int l64 = threadIdx.x & 63;
+    const bool idle = l64 / LX >= GPW;                                     // lanes beyond the last whole row group
+    const int lane = idle ? 0 : l64 % LX;                                  // position along x
+    const int wave = idle ? NG : (int)(threadIdx.x >> 6) * GPW + l64 / LX;  // row group
     const int tx = blockIdx.x % a.ntx, ty = blockIdx.x / a.ntx;
     const int w = a.w, h = a.h, pitch = a.pitch, K = a.K;
     const int ox = tx * (TW - 2 * a.HX), oy = ty * (TH - 2 * K);
     const int vx0 = ox + (tx > 0 ? a.HX : 0), vx1 = (tx == a.ntx - 1) ? w : ox + TW - a.HX;
     const int vy0 = oy + (ty > 0 ? K : 0), vy1 = (ty == a.nty - 1) ? h : oy + TH - K;
-    const int x0 = ox + lane * R, y0 = oy + wave * C;
-    // folded waves: lane LX's DPP "left neighbour" is the last lane of the other row group
+    const int x0 = idle ? (1 << 28) : ox + lane * R, y0 = oy + wave * C;  // idle lanes: outside every image
+    // folded waves: the DPP "left neighbour" of a row group's first lane belongs to another row group
     const float lfix = (LX == 64 || lane > 0) ? 1.0f : 0.0f;
 
     const float* __restrict__ ro = a.ro + (size_t)pair * kNF_RO * a.plane;
@@ -533,13 +537,17 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
 struct TileCfg {
     int R, C, NW, LX;
 };
-// Candidate tilings (R, C, NW, LX): 256x32 and 128x64 tiles, 512 threads, a 4x4 pixel patch per thread
-// (the packed-math kernel needs more than the 128 VGPRs a 1024-thread workgroup would leave it).
-constexpr TileCfg kCfgs[] = {{4, 4, 8, 64}, {4, 4, 8, 32}};
+// Candidate tilings (R, C, NW, LX): 256x32, 128x64, 84x96 and 64x128 tiles, 512 threads, a 4x4 pixel
+// patch per thread (the packed-math kernel needs more than the 128 VGPRs a 1024-thread workgroup
+// would leave it).  Every candidate costs the same time per workgroup-iteration.
+constexpr TileCfg kCfgs[] = {{4, 4, 8, 64}, {4, 4, 8, 32}, {4, 4, 8, 21}, {4, 4, 8, 16}};
 
 struct TilePick {
     int cfg, ntx, nty, HX, K;
 };
+
+constexpr double kTileLaunchUs = 14.0;
+inline double tile_iter_us(int LX) { return LX >= 32 ? 2.9 : 3.2; }
 
 int tiles_1d(int n, int T, int halo)
 {
@@ -563,10 +571,10 @@ TilePick pick_tiles(int w, int h, int K)
             if (2 * HX >= TW) continue;
         }
         const int ntx = tiles_1d(w, TW, HX), nty = tiles_1d(h, TH, k);
-        const long slots = (long)ntx * nty * TW * TH;
-        // measured on MI355X (profiles/README.md): an 8192-pixel tile costs ~12 us of exposed HBM round
-        // trip per launch plus ~2.9 us per inner iteration; cost per iteration of this level:
-        const double cost = (double)slots / 8192.0 * (12.0 / k + 2.9);
+        // measured on MI355X (tools/bench_tvl1_levels.py): a workgroup (one tile) costs ~14 us of exposed
+        // HBM round trip per launch plus ~2.9 us per inner iteration (3.2 us for the 3- and 4-fold
+        // waves); cost per iteration of this level:
+        const double cost = (double)ntx * nty * (kTileLaunchUs / k + tile_iter_us(kCfgs[i].LX));
         if (cost < best_cost) {
             best_cost = cost;
             best = TilePick{i, ntx, nty, HX, k};
@@ -585,13 +593,11 @@ TilePick pick_tiles_auto(int w, int h, int iters)
         const TilePick tp = pick_tiles(w, h, K);
         if (tp.K != K) continue;
         const int full = iters / K, rem = iters - full * K;
-        const int TWTH = 8192;
-        double cost = (double)full * tp.ntx * tp.nty * (12.0 + 2.9 * K);
+        double cost = (double)full * tp.ntx * tp.nty * (kTileLaunchUs + tile_iter_us(kCfgs[tp.cfg].LX) * K);
         if (rem) {
             const TilePick tr = pick_tiles(w, h, rem);
-            cost += (double)tr.ntx * tr.nty * (12.0 + 2.9 * tr.K) * ((double)rem / tr.K);
+            cost += (double)tr.ntx * tr.nty * (kTileLaunchUs + tile_iter_us(kCfgs[tr.cfg].LX) * tr.K) * ((double)rem / tr.K);
         }
-        (void)TWTH;
         if (cost < best_cost) {
             best_cost = cost;
             best = tp;
@@ -606,7 +612,9 @@ void launch_iter(const TilePick& tp, const IterArgs& a, int npairs, hipStream_t 
     const dim3 grid(tp.ntx * tp.nty, npairs);
     switch (tp.cfg) {
         case 0: k_iter_tile<2, 4, 8, 64, EPS, FAST><<<grid, 512, 0, st>>>(a); break;   // 256 x 32 tile
-        default: k_iter_tile<2, 4, 8, 32, EPS, FAST><<<grid, 512, 0, st>>>(a); break;  // 128 x 64 tile (folded waves)
+        case 1: k_iter_tile<2, 4, 8, 32, EPS, FAST><<<grid, 512, 0, st>>>(a); break;   // 128 x 64 (2 row groups per wave)
+        case 2: k_iter_tile<2, 4, 8, 21, EPS, FAST><<<grid, 512, 0, st>>>(a); break;   // 84 x 96 (3 row groups, lane 63 idle)
+        default: k_iter_tile<2, 4, 8, 16, EPS, FAST><<<grid, 512, 0, st>>>(a); break;  // 64 x 128 (4 row groups)
     }
 }
 
