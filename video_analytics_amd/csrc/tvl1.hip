@@ -120,8 +120,58 @@ __global__ void k_grad(float* __restrict__ pyr, int w, int h, int pitch, size_t 
 
 // ---------------------------------------------------------------- per-warp kernel ------------
 
-// S5.  One thread per pixel of one pair.  The 12 bilinear taps are data-dependent gathers served
-// by L1/L2 (25 launches per pair against 7500 inner iterations: lower-order).
+// S3 for the three warped images at once, with the wave supplying half of the taps: consecutive lanes
+// are consecutive pixels of a row, and wherever the flow is smooth lane i+1's left taps (x0+1, y0),
+// (x0+1, y1) ARE lane i's right taps, so they arrive by a wave shuffle instead of a second gather
+// (same values, same arithmetic: the result is bit-identical to bilinear()).
+__device__ __forceinline__ void bilinear3_shfl(const float* __restrict__ I1, size_t plane, int w, int h, int pitch, float x,
+                                               float y, bool active, float& v0, float& v1, float& v2)
+{
+    x = fminf(fmaxf(x, 0.0f), (float)(w - 1));
+    y = fminf(fmaxf(y, 0.0f), (float)(h - 1));
+    const int x0 = (int)x, y0 = (int)y;
+    const int x1 = d_min(x0 + 1, w - 1), y1 = d_min(y0 + 1, h - 1);
+    const float ax = x - (float)x0, ay = y - (float)y0;
+    const int o00 = y0 * pitch + x0, o10 = y1 * pitch + x0;
+    float a[3], c[3], b[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a[k] = active ? I1[k * plane + o00] : 0.0f;
+        c[k] = active ? I1[k * plane + o10] : 0.0f;
+    }
+    // the neighbouring lane's left column is my right column iff it starts one pixel to the right on the same rows
+    const int nx0 = __shfl_down(x0, 1), ny0 = __shfl_down(y0, 1), ny1 = __shfl_down(y1, 1);
+    const bool nact = __shfl_down((int)active, 1) != 0;
+    const bool from_lane = (threadIdx.x & 63) != 63 && nact && nx0 == x1 && ny0 == y0 && ny1 == y1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float na = __shfl_down(a[k], 1), nc = __shfl_down(c[k], 1);
+        if (x1 == x0) {  // clamped at the right border: the right taps are the left taps
+            b[k] = a[k];
+            d[k] = c[k];
+        } else if (from_lane) {
+            b[k] = na;
+            d[k] = nc;
+        } else {
+            b[k] = active ? I1[k * plane + y0 * pitch + x1] : 0.0f;
+            d[k] = active ? I1[k * plane + y1 * pitch + x1] : 0.0f;
+        }
+    }
+    float r[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float top = fmaf(ax, b[k] - a[k], a[k]);
+        const float bot = fmaf(ax, d[k] - c[k], c[k]);
+        r[k] = fmaf(ay, bot - top, top);
+    }
+    v0 = r[0];
+    v1 = r[1];
+    v2 = r[2];
+}
+
+// S5.  One thread per pixel of one pair; the 12 bilinear taps of a pixel are 6 L1/L2-served gathers plus
+// 6 wave shuffles where the flow is smooth (25 launches per pair against 7500 inner iterations:
+// lower-order).
 __global__ void k_warp(const float* __restrict__ pyr, size_t plane, int w, int h, int pitch, int fps,
                        const float* __restrict__ stA, const float* __restrict__ stB, const int* __restrict__ sel, int cur,
                        int* __restrict__ base, float* __restrict__ ro)
@@ -130,19 +180,18 @@ __global__ void k_warp(const float* __restrict__ pyr, size_t plane, int w, int h
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int which = sel ? sel[pair] : cur;
     if (base && idx == 0) base[pair] = which;
-    if (idx >= w * h) return;
-    const int y = idx / w, x = idx - y * w;
+    const bool active = idx < w * h;  // inactive lanes still take part in the shuffles
+    const int y = active ? idx / w : 0, x = active ? idx - y * w : 0;
     const int seq = pair / (fps - 1), k = pair - seq * (fps - 1);
     const int f0 = seq * fps + k;
     const float* I0 = pyr + (size_t)f0 * 3 * plane;
     const float* I1 = pyr + (size_t)(f0 + 1) * 3 * plane;
     const float* st = (which ? stB : stA) + (size_t)pair * kNF_STATE * plane;
     const size_t o = (size_t)y * pitch + x;
-    const float u1 = st[o], u2 = st[plane + o];
-    const float fxp = (float)x + u1, fyp = (float)y + u2;
-    const float Iw = bilinear(I1, w, h, pitch, fxp, fyp);
-    const float Iwx = bilinear(I1 + plane, w, h, pitch, fxp, fyp);
-    const float Iwy = bilinear(I1 + 2 * plane, w, h, pitch, fxp, fyp);
+    const float u1 = active ? st[o] : 0.0f, u2 = active ? st[plane + o] : 0.0f;
+    float Iw, Iwx, Iwy;
+    bilinear3_shfl(I1, plane, w, h, pitch, (float)x + u1, (float)y + u2, active, Iw, Iwx, Iwy);
+    if (!active) return;
     const float grad = fmaf(Iwy, Iwy, Iwx * Iwx);
     float* r = ro + (size_t)pair * kNF_RO * plane;
     r[o] = Iwx;
