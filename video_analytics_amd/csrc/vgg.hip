@@ -23,10 +23,25 @@
 //     keeping the reference's CHW-major flatten order c*49+h*7+w (Sheet03/spatialModel.py:213).
 #include "va_internal.h"
 #include <cstring>
+#include <type_traits>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));       // native vectors for the staging registers:
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));    // arrays of HIP's float4/uint4 structs were kept in scratch
+
+// Compile-time loop: the body sees its index as a constant expression, so register arrays indexed by it can
+// never be demoted to scratch (a `#pragma unroll` loop over rb[] in the conv kernels was: hipcc kept the
+// prefetched weight tile in private memory and waited for every global load right after issuing it).
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
 constexpr int kBK = 16;       // K chunk per LDS tile (floats)
 constexpr int kLdsStride = 20;  // floats per LDS row: 80 B keeps ds_read_b128 conflict-free
@@ -200,37 +215,44 @@ __global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
 
     const int cchunks = Cin / BK;
     const int T = 9 * cchunks;
-    float4 ra[A_PASSES], rb[B_PASSES];
+    // Staging registers of the next K tile.  (Written as macros, not lambdas: with the arrays captured by
+    // reference hipcc kept rb[] in scratch and waited for every prefetch right after issuing it.)
+    f32x4 ra[A_PASSES], rb[B_PASSES];
+#define VA_CONV_GLOAD(t_)                                                                                       \
+    {                                                                                                           \
+        const int kp_ = (t_) / cchunks, c0_ = ((t_)-kp_ * cchunks) * BK;                                        \
+        const int ky_ = kp_ / 3 - 1, kx_ = kp_ % 3 - 1;                                                         \
+        static_for<A_PASSES>([&](auto I) {                                                                      \
+            constexpr int i = decltype(I)::value;                                                               \
+            const int yy_ = ay[i] + ky_, xx_ = ax[i] + kx_;                                                     \
+            const bool ok_ = aok[i] && yy_ >= 0 && yy_ < H && xx_ >= 0 && xx_ < W;                              \
+            ra[i] = ok_ ? *reinterpret_cast<const f32x4*>(a.in + apix[i] + ((long)ky_ * W + kx_) * Cin + c0_)   \
+                        : f32x4{0.f, 0.f, 0.f, 0.f};                                                            \
+        });                                                                                                     \
+        static_for<B_PASSES>([&](auto I) {                                                                      \
+            constexpr int i = decltype(I)::value;                                                               \
+            rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + (size_t)kp_ * Cin + c0_);                         \
+        });                                                                                                     \
+    }
+#define VA_CONV_LSTORE(buf_)                                                                                    \
+    {                                                                                                           \
+        static_for<A_PASSES>([&](auto I) {                                                                      \
+            constexpr int i = decltype(I)::value;                                                               \
+            *reinterpret_cast<f32x4*>(&sA[buf_][(rowbase + A_ROWS_PER_PASS * i) * LDS + 4 * q]) = ra[i];         \
+        });                                                                                                     \
+        static_for<B_PASSES>([&](auto I) {                                                                      \
+            constexpr int i = decltype(I)::value;                                                               \
+            *reinterpret_cast<f32x4*>(&sB[buf_][(rowbase + A_ROWS_PER_PASS * i) * LDS + 4 * q]) = rb[i];         \
+        });                                                                                                     \
+    }
 
-    auto gload = [&](int t) {
-        const int kp = t / cchunks, c0 = (t - kp * cchunks) * BK;
-        const int ky = kp / 3 - 1, kx = kp % 3 - 1;
-#pragma unroll
-        for (int i = 0; i < A_PASSES; ++i) {
-            const int yy = ay[i] + ky, xx = ax[i] + kx;
-            const bool ok = aok[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            ra[i] = ok ? *reinterpret_cast<const float4*>(a.in + apix[i] + ((long)ky * W + kx) * Cin + c0)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < B_PASSES; ++i) rb[i] = *reinterpret_cast<const float4*>(wrow[i] + (size_t)kp * Cin + c0);
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_PASSES; ++i)
-            *reinterpret_cast<float4*>(&sA[buf][(rowbase + A_ROWS_PER_PASS * i) * LDS + 4 * q]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_PASSES; ++i)
-            *reinterpret_cast<float4*>(&sB[buf][(rowbase + A_ROWS_PER_PASS * i) * LDS + 4 * q]) = rb[i];
-    };
-
-    gload(0);
-    lstore(0);
+    VA_CONV_GLOAD(0)
+    VA_CONV_LSTORE(0)
     __syncthreads();
     const int r31 = lane & 31, hh = lane >> 5;
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
-        if (t + 1 < T) gload(t + 1);
+        if (t + 1 < T) VA_CONV_GLOAD(t + 1)
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
             float4 fa[MT], fb[NT];
@@ -250,9 +272,11 @@ __global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt].w, fb[nt].w, acc[mt][nt], 0, 0, 0);
                 }
         }
-        if (t + 1 < T) lstore(buf ^ 1);
+        if (t + 1 < T) VA_CONV_LSTORE(buf ^ 1)
         __syncthreads();
     }
+#undef VA_CONV_GLOAD
+#undef VA_CONV_LSTORE
 
     // epilogue: bias + ReLU (+ 2x2 max-pool over the 4 registers reg&3 of a lane)
 #pragma unroll
@@ -375,35 +399,42 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma_bf16(ConvArgsBf a)
 
     const int cchunks = Cin / kBfBK;
     const int T = 9 * cchunks;
-    uint4 ra[A_PASSES], rb[B_PASSES];
-    auto gload = [&](int t) {
-        const int kp = t / cchunks, c0 = (t - kp * cchunks) * kBfBK;
-        const int ky = kp / 3 - 1, kx = kp % 3 - 1;
-#pragma unroll
-        for (int i = 0; i < A_PASSES; ++i) {
-            const int yy = ay[i] + ky, xx = ax[i] + kx;
-            const bool ok = aok[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            ra[i] = ok ? *reinterpret_cast<const uint4*>(a.in + apix[i] + ((long)ky * W + kx) * Cin + c0) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < B_PASSES; ++i) rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (size_t)kp * Cin + c0);
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_PASSES; ++i)
-            *reinterpret_cast<uint4*>(&sA[buf][(rowbase + ROWS_PER_PASS * i) * kBfLds + 8 * q]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_PASSES; ++i)
-            *reinterpret_cast<uint4*>(&sB[buf][(rowbase + ROWS_PER_PASS * i) * kBfLds + 8 * q]) = rb[i];
-    };
+    u32x4 ra[A_PASSES], rb[B_PASSES];
+#define VA_CONV_GLOAD(t_)                                                                                       \
+    {                                                                                                           \
+        const int kp_ = (t_) / cchunks, c0_ = ((t_)-kp_ * cchunks) * kBfBK;                                     \
+        const int ky_ = kp_ / 3 - 1, kx_ = kp_ % 3 - 1;                                                         \
+        static_for<A_PASSES>([&](auto I) {                                                                      \
+            constexpr int i = decltype(I)::value;                                                               \
+            const int yy_ = ay[i] + ky_, xx_ = ax[i] + kx_;                                                     \
+            const bool ok_ = aok[i] && yy_ >= 0 && yy_ < H && xx_ >= 0 && xx_ < W;                              \
+            ra[i] = ok_ ? *reinterpret_cast<const u32x4*>(a.in + apix[i] + ((long)ky_ * W + kx_) * Cin + c0_)   \
+                        : u32x4{0u, 0u, 0u, 0u};                                                                \
+        });                                                                                                     \
+        static_for<B_PASSES>([&](auto I) {                                                                      \
+            constexpr int i = decltype(I)::value;                                                               \
+            rb[i] = *reinterpret_cast<const u32x4*>(wrow[i] + (size_t)kp_ * Cin + c0_);                         \
+        });                                                                                                     \
+    }
+#define VA_CONV_LSTORE(buf_)                                                                                    \
+    {                                                                                                           \
+        static_for<A_PASSES>([&](auto I) {                                                                      \
+            constexpr int i = decltype(I)::value;                                                               \
+            *reinterpret_cast<u32x4*>(&sA[buf_][(rowbase + ROWS_PER_PASS * i) * kBfLds + 8 * q]) = ra[i];        \
+        });                                                                                                     \
+        static_for<B_PASSES>([&](auto I) {                                                                      \
+            constexpr int i = decltype(I)::value;                                                               \
+            *reinterpret_cast<u32x4*>(&sB[buf_][(rowbase + ROWS_PER_PASS * i) * kBfLds + 8 * q]) = rb[i];        \
+        });                                                                                                     \
+    }
 
-    gload(0);
-    lstore(0);
+    VA_CONV_GLOAD(0)
+    VA_CONV_LSTORE(0)
     __syncthreads();
     const int r31 = lane & 31, hh = lane >> 5;
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
-        if (t + 1 < T) gload(t + 1);
+        if (t + 1 < T) VA_CONV_GLOAD(t + 1)
 #pragma unroll
         for (int ks = 0; ks < kBfBK / 16; ++ks) {
             bf16x8 fa[MT], fb[NT];
@@ -419,9 +450,11 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma_bf16(ConvArgsBf a)
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
         }
-        if (t + 1 < T) lstore(buf ^ 1);
+        if (t + 1 < T) VA_CONV_LSTORE(buf ^ 1)
         __syncthreads();
     }
+#undef VA_CONV_GLOAD
+#undef VA_CONV_LSTORE
 
     // epilogue: bias + ReLU (+ 2x2 max-pool over the 4 registers reg&3 of a lane), fp32 math, bf16/f32 store
 #pragma unroll
