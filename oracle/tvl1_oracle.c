@@ -52,7 +52,8 @@
  *               written as a clamp: the three IPOL cases coincide with it)
  *         v1  = fmaf(fi,I1wx,u1);  v2 = fmaf(fi,I1wy,u2);
  *         u1' = fmaf(theta, div(p11,p12), v1);  (same for u2)
- *         d1  = fmaf(taut, sqrtf(fmaf(u1y,u1y, u1x*u1x)), 1); d2 likewise from u2;
+ *         d1  = fmaf(taut, sqrtf(fmaf(u1y,u1y, fmaf(u1x,u1x, 2^-100))), 1); d2 likewise from u2
+ *               (|grad u| regularised by 2^-50: never 0 under the square root);
  *         rinv = 1/(d1*d2); r1 = d2*rinv; r2 = d1*rinv;   (1/d1 and 1/d2 from ONE division)
  *         p11 = fmaf(taut,u1x,p11)*r1; p12 = fmaf(taut,u1y,p12)*r1; p21, p22 with r2
  *       with l_t = lambda*theta, taut = tau/theta, backward-difference
@@ -92,6 +93,7 @@ typedef struct ora_tvl1_params {
 
 #define ORA_MAX_SCALES 16
 #define ORA_MAX_RADIUS 8
+#define ORA_NORM_REG 0x1p-100f /* S6: regulariser of |grad u|^2 */
 
 static int imin(int a, int b) { return a < b ? a : b; }
 static int imax(int a, int b) { return a > b ? a : b; }
@@ -262,8 +264,8 @@ long ora_tvl1_level(const float* I0, const float* I1, const float* I1x, const fl
                     u1y = y < h - 1 ? u1[i + w] - u1[i] : 0.0f;
                     u2x = x < w - 1 ? u2[i + 1] - u2[i] : 0.0f;
                     u2y = y < h - 1 ? u2[i + w] - u2[i] : 0.0f;
-                    d1 = fmaf(taut, sqrtf(fmaf(u1y, u1y, u1x * u1x)), 1.0f);
-                    d2 = fmaf(taut, sqrtf(fmaf(u2y, u2y, u2x * u2x)), 1.0f);
+                    d1 = fmaf(taut, sqrtf(fmaf(u1y, u1y, fmaf(u1x, u1x, ORA_NORM_REG))), 1.0f);
+                    d2 = fmaf(taut, sqrtf(fmaf(u2y, u2y, fmaf(u2x, u2x, ORA_NORM_REG))), 1.0f);
                     rinv = 1.0f / (d1 * d2); /* one division per pixel: 1/d1 = d2/(d1 d2) */
                     r1 = d2 * rinv;
                     r2 = d1 * rinv;

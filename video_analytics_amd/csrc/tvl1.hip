@@ -295,6 +295,13 @@ __device__ __forceinline__ float dpp_from_right(float v)  // lane i <- lane i+1,
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f32
+// a - b as one v_sub_f32 the vectoriser cannot re-pack (see the x differences in k_iter_tile)
+__device__ __forceinline__ float sub_s(float a, float b)
+{
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 
 // Correctly rounded square root and reciprocal from the 1-ulp hardware seeds with packed FMAs only
@@ -308,9 +315,9 @@ __device__ __forceinline__ f2 sqrt_exact_pk(f2 s)  // s in [2^-100, 1e30]
     const f2 y = f2{__builtin_amdgcn_rsqf(s.x), __builtin_amdgcn_rsqf(s.y)};
     const f2 g0 = s * y, h0 = y * 0.5f;
     const f2 r = pk_fma(-h0, g0, splat(0.5f));
-    const f2 g1 = pk_fma(g0, r, g0), h1 = pk_fma(h0, r, h0);
+    const f2 g1 = pk_fma(g0, r, g0);
     const f2 d = pk_fma(-g1, g1, s);
-    return pk_fma(d, h1, g1);
+    return pk_fma(d, h0, g1);  // the 1-ulp h0 suffices for the last correction (checked exhaustively)
 }
 __device__ __forceinline__ f2 rcp_exact_pk(f2 d)  // d in [1, 1e30]
 {
@@ -373,8 +380,9 @@ template <int RP, int C, int NW, int LX, bool EPS, bool FAST>
 __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
 {
     constexpr int R = 2 * RP, TW = LX * R, GPW = 64 / LX, NG = NW * GPW, TH = NG * C;
-    // row NG of the exchange arrays is a dummy for idle lanes (64 % LX != 0)
-    __shared__ __attribute__((aligned(16))) float sP12[NG + 1][TW], sP22[NG + 1][TW], sU1[NG + 1][TW], sU2[NG + 1][TW];
+    // row NG of the exchange arrays is a dummy for idle lanes (64 % LX != 0); row NG + 1 stays zero: it is
+    // the "row above" of the first and the "row below" of the last row group
+    __shared__ __attribute__((aligned(16))) float sP12[NG + 2][TW], sP22[NG + 2][TW], sU1[NG + 2][TW], sU2[NG + 2][TW];
     __shared__ unsigned long long sErr;
 
     const int pair = blockIdx.y;
@@ -439,12 +447,13 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
     f2* const rowP22 = reinterpret_cast<f2*>(&sP22[wave][lane * R]);
     f2* const rowU1 = reinterpret_cast<f2*>(&sU1[wave][lane * R]);
     f2* const rowU2 = reinterpret_cast<f2*>(&sU2[wave][lane * R]);
-    const f2* const upP12 = reinterpret_cast<const f2*>(&sP12[wave > 0 ? wave - 1 : 0][lane * R]);
-    const f2* const upP22 = reinterpret_cast<const f2*>(&sP22[wave > 0 ? wave - 1 : 0][lane * R]);
-    const f2* const dnU1 = reinterpret_cast<const f2*>(&sU1[wave < NG - 1 ? wave + 1 : 0][lane * R]);
-    const f2* const dnU2 = reinterpret_cast<const f2*>(&sU2[wave < NG - 1 ? wave + 1 : 0][lane * R]);
-    const float upok = wave > 0 ? 1.0f : 0.0f, dnok = wave < NG - 1 ? 1.0f : 0.0f;
+    const int upRow = wave > 0 ? wave - 1 : NG + 1, dnRow = wave < NG - 1 ? wave + 1 : NG + 1;
+    const f2* const upP12 = reinterpret_cast<const f2*>(&sP12[upRow][lane * R]);
+    const f2* const upP22 = reinterpret_cast<const f2*>(&sP22[upRow][lane * R]);
+    const f2* const dnU1 = reinterpret_cast<const f2*>(&sU1[dnRow][lane * R]);
+    const f2* const dnU2 = reinterpret_cast<const f2*>(&sU2[dnRow][lane * R]);
 
+    for (int i = threadIdx.x; i < TW; i += NW * 64) sP12[NG + 1][i] = sP22[NG + 1][i] = sU1[NG + 1][i] = sU2[NG + 1][i] = 0.0f;
 #pragma clang loop unroll(full)
     for (int j = 0; j < RP; ++j) {
         rowP12[j] = p12[C - 1][j];
@@ -461,11 +470,15 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
         f2 A12[RP], A22[RP];
 #pragma clang loop unroll(full)
         for (int j = 0; j < RP; ++j) {
-            A12[j] = upP12[j] * upok;
-            A22[j] = upP22[j] * upok;
+            A12[j] = upP12[j];
+            A22[j] = upP22[j];
         }
+        // Row order: row 0 needs the neighbour row fetched from LDS just above (its latency hides behind
+        // row 1) and produces the row the group above waits for (stored right after it, so that the
+        // store's latency hides behind rows 2.. before the barrier).
 #pragma clang loop unroll(full)
-        for (int c = 0; c < C; ++c) {
+        for (int cc = 0; cc < C; ++cc) {
+            const int c = (C > 1 && cc < 2) ? 1 - cc : cc;
             float l11 = dpp_from_left(p11[c][RP - 1].y), l21 = dpp_from_left(p21[c][RP - 1].y);
             if constexpr (LX != 64) {
                 l11 *= lfix;
@@ -473,12 +486,14 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
             }
 #pragma clang loop unroll(full)
             for (int j = 0; j < RP; ++j) {
-                const f2 L11 = f2{j > 0 ? p11[c][j > 0 ? j - 1 : 0].y : l11, p11[c][j].x};
-                const f2 L21 = f2{j > 0 ? p21[c][j > 0 ? j - 1 : 0].y : l21, p21[c][j].x};
+                // x differences as plain v_sub_f32 (2 cycles each; a packed subtract would need a
+                // v_pk_mov shuffle first), y differences packed
+                const f2 dx11 = f2{sub_s(p11[c][j].x, j > 0 ? p11[c][j > 0 ? j - 1 : 0].y : l11), sub_s(p11[c][j].y, p11[c][j].x)};
+                const f2 dx21 = f2{sub_s(p21[c][j].x, j > 0 ? p21[c][j > 0 ? j - 1 : 0].y : l21), sub_s(p21[c][j].y, p21[c][j].x)};
                 const f2 a12 = c > 0 ? p12[c > 0 ? c - 1 : 0][j] : A12[j];
                 const f2 a22 = c > 0 ? p22[c > 0 ? c - 1 : 0][j] : A22[j];
-                const f2 div1 = (p11[c][j] - L11) + (p12[c][j] - a12);
-                const f2 div2 = (p21[c][j] - L21) + (p22[c][j] - a22);
+                const f2 div1 = dx11 + (p12[c][j] - a12);
+                const f2 div2 = dx21 + (p22[c][j] - a22);
                 const f2 rho = pk_fma(wy[c][j], u2[c][j], pk_fma(wx[c][j], u1[c][j], rc[c][j]));
                 const f2 t = -rho * ig[c][j];
                 const f2 fi = f2{__builtin_amdgcn_fmed3f(t.x, -l_t, l_t), __builtin_amdgcn_fmed3f(t.y, -l_t, l_t)};
@@ -498,12 +513,14 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
                 u1[c][j] = n1;
                 u2[c][j] = n2;
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep rows in program order: bounds register pressure
-        }
+            if (c == 0) {
 #pragma clang loop unroll(full)
-        for (int j = 0; j < RP; ++j) {
-            rowU1[j] = u1[0][j];
-            rowU2[j] = u2[0][j];
+                for (int j = 0; j < RP; ++j) {
+                    rowU1[j] = u1[0][j];
+                    rowU2[j] = u2[0][j];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep rows in program order: bounds register pressure
         }
         __syncthreads();
 
@@ -511,21 +528,25 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
         f2 B1[RP], B2[RP];
 #pragma clang loop unroll(full)
         for (int j = 0; j < RP; ++j) {
-            B1[j] = dnU1[j] * dnok;
-            B2[j] = dnU2[j] * dnok;
+            B1[j] = dnU1[j];
+            B2[j] = dnU2[j];
         }
+        // Row order 0 .. C-3, C-1, C-2: the last row needs the LDS fetch and produces the exchanged row
 #pragma clang loop unroll(full)
-        for (int c = 0; c < C; ++c) {
+        for (int cc = 0; cc < C; ++cc) {
+            const int c = (C > 1 && cc >= C - 2) ? 2 * C - 3 - cc : cc;
             const float r1 = dpp_from_right(u1[c][0].x), r2 = dpp_from_right(u2[c][0].x);
 #pragma clang loop unroll(full)
             for (int j = 0; j < RP; ++j) {
-                const f2 R1 = f2{u1[c][j].y, j < RP - 1 ? u1[c][j < RP - 1 ? j + 1 : 0].x : r1};
-                const f2 R2 = f2{u2[c][j].y, j < RP - 1 ? u2[c][j < RP - 1 ? j + 1 : 0].x : r2};
+                const f2 d1x = f2{sub_s(u1[c][j].y, u1[c][j].x), sub_s(j < RP - 1 ? u1[c][j < RP - 1 ? j + 1 : 0].x : r1, u1[c][j].y)};
+                const f2 d2x = f2{sub_s(u2[c][j].y, u2[c][j].x), sub_s(j < RP - 1 ? u2[c][j < RP - 1 ? j + 1 : 0].x : r2, u2[c][j].y)};
                 const f2 b1 = c < C - 1 ? u1[c < C - 1 ? c + 1 : 0][j] : B1[j];
                 const f2 b2 = c < C - 1 ? u2[c < C - 1 ? c + 1 : 0][j] : B2[j];
-                const f2 u1x = (R1 - u1[c][j]) * mx[j], u1y = (b1 - u1[c][j]) * my[c];
-                const f2 u2x = (R2 - u2[c][j]) * mx[j], u2y = (b2 - u2[c][j]) * my[c];
-                const f2 s1 = pk_fma(u1y, u1y, u1x * u1x), s2 = pk_fma(u2y, u2y, u2x * u2x);
+                const f2 u1x = d1x * mx[j], u1y = (b1 - u1[c][j]) * my[c];
+                const f2 u2x = d2x * mx[j], u2y = (b2 - u2[c][j]) * my[c];
+                // |grad u|^2 + 2^-100 (S6): the regulariser rides in the first FMA
+                const f2 s1 = pk_fma(u1y, u1y, pk_fma(u1x, u1x, splat(kSqrtReg)));
+                const f2 s2 = pk_fma(u2y, u2y, pk_fma(u2x, u2x, splat(kSqrtReg)));
                 f2 q1, q2;
                 if constexpr (FAST) {  // 1-ulp hardware sqrt / rcp (va_tvl1_params.fast_math)
                     const f2 g1 = f2{__builtin_amdgcn_sqrtf(s1.x), __builtin_amdgcn_sqrtf(s1.y)};
@@ -534,11 +555,9 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
                     q1 = f2{__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)};
                     q2 = f2{__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)};
                 } else {
-                    // exact contract: correctly rounded sqrt, ONE correctly rounded division per pixel.
-                    // s + 2^-100 keeps the argument in sqrt_exact_pk's domain and never changes
-                    // d = fma(taut, sqrt(s), 1): it alters s only below 1.3e-23, where taut*sqrt(s)
-                    // < 2^-25 (taut <= 1000 is checked on the host) and d rounds to 1 either way.
-                    const f2 g1 = sqrt_exact_pk(s1 + kSqrtReg), g2 = sqrt_exact_pk(s2 + kSqrtReg);
+                    // exact contract: correctly rounded sqrt, ONE correctly rounded division per pixel
+                    // (s >= 2^-100: inside sqrt_exact_pk's domain).
+                    const f2 g1 = sqrt_exact_pk(s1), g2 = sqrt_exact_pk(s2);
                     const f2 d1 = pk_fma(taut, g1, one), d2 = pk_fma(taut, g2, one);
                     const f2 rinv = rcp_exact_pk(d1 * d2);
                     q1 = d2 * rinv;
@@ -549,12 +568,14 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
                 p21[c][j] = pk_fma(taut, u2x, p21[c][j]) * q2;
                 p22[c][j] = pk_fma(taut, u2y, p22[c][j]) * q2;
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            if (c == C - 1) {
 #pragma clang loop unroll(full)
-        for (int j = 0; j < RP; ++j) {
-            rowP12[j] = p12[C - 1][j];
-            rowP22[j] = p22[C - 1][j];
+                for (int j = 0; j < RP; ++j) {
+                    rowP12[j] = p12[C - 1][j];
+                    rowP22[j] = p22[C - 1][j];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
