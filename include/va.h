@@ -123,6 +123,10 @@ typedef struct va_tvl1_params {
                          1: the two special functions of the dual update use the 1-ulp hardware
                          v_sqrt_f32 / v_rcp_f32 (1.6x faster inner iterations; flow within ~1e-4 px
                          of the exact mode, tested with a 1e-3 px tolerance). */
+    int tile_mask;    /* tuning/testing: bit i allows register-tile candidate i of the inner-iteration
+                         kernel (bits 0-3: 256x32, 128x64, 84x96, 64x128 pixels, one 8-wave workgroup
+                         per CU; bits 4-7: 256x16, 128x32, 84x48, 64x64, two 4-wave workgroups per
+                         CU).  0 (default) = all.  Results do not depend on it. */
 } va_tvl1_params;
 
 void va_tvl1_default_params(va_tvl1_params* p);

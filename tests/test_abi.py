@@ -34,7 +34,7 @@ def test_host_only_entry_points(lib):
     from video_analytics_amd import _ffi
     p = _ffi.default_tvl1_params()
     assert (round(p.tau, 4), round(p.lambda_, 4), round(p.theta, 4), p.nscales, p.warps, p.iters) == (0.25, 0.15, 0.3, 5, 5, 300)
-    assert abs(p.epsilon - 0.01) < 1e-9 and abs(p.scale_step - 0.8) < 1e-7 and p.block_iters == 0 and p.fast_math == 0
+    assert abs(p.epsilon - 0.01) < 1e-9 and abs(p.scale_step - 0.8) < 1e-7 and p.block_iters == 0 and p.fast_math == 0 and p.tile_mask == 0
     from video_analytics_amd.flow import pyramid_sizes
     for (w, h) in [(224, 224), (1280, 720), (320, 240), (64, 48), (17, 300)]:
         assert pyramid_sizes(w, h) == tvl1_oracle.pyramid_sizes(w, h)

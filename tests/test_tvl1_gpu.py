@@ -20,7 +20,7 @@ def _frames(n_seq, n_frames, H, W, seed):
 
 def _run_both(oracle_tvl1, gray, **kw):
     from video_analytics_amd import flow as vflow
-    okw = {("lambda_" if k == "lambda" else k): v for k, v in kw.items() if k != "block_iters"}
+    okw = {("lambda_" if k == "lambda" else k): v for k, v in kw.items() if k not in ("block_iters", "tile_mask")}
     ref = oracle_tvl1.tvl1_flow(gray.numpy(), oracle_tvl1.default_params(**okw), nthreads=8)
     out = vflow.tvl1_flow(gray.cuda(), **kw)
     torch.cuda.synchronize()
@@ -49,6 +49,18 @@ def test_shapes_fixed_bit_exact(oracle_tvl1, H, W):
 def test_block_depth_and_remainders_bit_exact(oracle_tvl1, block_iters, iters):
     gray = _frames(2, 2, 224, 224, seed=13)
     ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=2, block_iters=block_iters)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
+@pytest.mark.parametrize("bit", range(8))
+def test_every_register_tile_candidate_bit_exact(oracle_tvl1, bit):
+    # tile_mask forces one candidate of the inner-iteration kernel (8-wave 256x32 .. 64x128 and 4-wave
+    # 256x16 .. 64x64): 300x150 needs several tiles with halos in x and in y for each of them; the
+    # epsilon run exercises the same instantiations with the stopping rule
+    gray = _frames(1, 3, 150, 300, seed=21 + bit)
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=17, warps=2, nscales=2, block_iters=5, tile_mask=1 << bit)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.02, iters=40, warps=1, nscales=2, tile_mask=1 << bit)
     assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 

@@ -35,6 +35,7 @@ class Tvl1Params(ctypes.Structure):
         ("scale_step", ctypes.c_float),
         ("block_iters", ctypes.c_int),
         ("fast_math", ctypes.c_int),
+        ("tile_mask", ctypes.c_int),
     ]
 
 

@@ -24,6 +24,7 @@
 #include "va_internal.h"
 #include <cmath>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 
@@ -304,28 +305,26 @@ __device__ __forceinline__ float sub_s(float a, float b)
 }
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 
-// Correctly rounded square root and reciprocal from the 1-ulp hardware seeds with packed FMAs only
-// (Markstein-style: no denormal scaling, no special-case selects).  Both are bit-identical to the
-// IEEE sqrtf() / 1.0f/x of the arithmetic contract on their whole domain: va_selftest_exact_math()
-// compares them EXHAUSTIVELY (every float in [2^-100, 1e30] resp. [1, 1e30]) against the compiler's
-// correctly rounded expansions; tests/test_tvl1_gpu.py runs that check.
+// Correctly rounded square root and reciprocal from the hardware seeds with packed FMAs only (one
+// Newton step on the exact FMA residual; no denormal scaling, no special-case selects).  Both are
+// bit-identical to the IEEE sqrtf() / 1.0f/x of the arithmetic contract on their whole domain:
+// va_selftest_exact_math() compares them EXHAUSTIVELY (every float in [2^-100, 1e30] resp. [1, 1e30])
+// against the compiler's correctly rounded expansions; tests/test_tvl1_gpu.py runs that check.  (The
+// raw seeds fail it on 31 % resp. 11 % of the inputs; gfx950's v_rsq_f32 / v_rcp_f32 are accurate
+// enough that the second refinement step of the textbook sequences is never needed.)
 constexpr float kSqrtReg = 7.888609052210118e-31f;  // 2^-100
 __device__ __forceinline__ f2 sqrt_exact_pk(f2 s)  // s in [2^-100, 1e30]
 {
     const f2 y = f2{__builtin_amdgcn_rsqf(s.x), __builtin_amdgcn_rsqf(s.y)};
-    const f2 g0 = s * y, h0 = y * 0.5f;
-    const f2 r = pk_fma(-h0, g0, splat(0.5f));
-    const f2 g1 = pk_fma(g0, r, g0);
-    const f2 d = pk_fma(-g1, g1, s);
-    return pk_fma(d, h0, g1);  // the 1-ulp h0 suffices for the last correction (checked exhaustively)
+    const f2 g = s * y, h = y * 0.5f;
+    const f2 d = pk_fma(-g, g, s);  // exact residual s - g^2
+    return pk_fma(d, h, g);
 }
 __device__ __forceinline__ f2 rcp_exact_pk(f2 d)  // d in [1, 1e30]
 {
     const f2 r = f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    const f2 e0 = pk_fma(-d, r, splat(1.0f));
-    const f2 r1 = pk_fma(e0, r, r);
-    const f2 e1 = pk_fma(-d, r1, splat(1.0f));
-    return pk_fma(e1, r1, r1);
+    const f2 e = pk_fma(-d, r, splat(1.0f));  // exact residual 1 - d r
+    return pk_fma(e, r, r);
 }
 
 __global__ void k_selftest_exact_math(unsigned lo, unsigned long long n, unsigned long long* bad)
@@ -610,14 +609,33 @@ struct TileCfg {
 // Candidate tilings (R, C, NW, LX): 256x32, 128x64, 84x96 and 64x128 tiles, 512 threads, a 4x4 pixel
 // patch per thread (the packed-math kernel needs more than the 128 VGPRs a 1024-thread workgroup
 // would leave it).  Every candidate costs the same time per workgroup-iteration.
-constexpr TileCfg kCfgs[] = {{4, 4, 8, 64}, {4, 4, 8, 32}, {4, 4, 8, 21}, {4, 4, 8, 16}};
+constexpr TileCfg kCfgs[] = {{4, 4, 8, 64}, {4, 4, 8, 32}, {4, 4, 8, 21}, {4, 4, 8, 16},
+                             {4, 4, 4, 64}, {4, 4, 4, 32}, {4, 4, 4, 21}, {4, 4, 4, 16}};
+constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
 struct TilePick {
     int cfg, ntx, nty, HX, K;
 };
 
-constexpr double kTileLaunchUs = 14.0;
-inline double tile_iter_us(int LX) { return LX >= 32 ? 2.9 : 3.2; }
+// Cost of a workgroup in CU-microseconds, measured on MI355X (tools/bench_tvl1_levels.py,
+// tools/microbench_tvl1_tile.py): exposed HBM round trip per launch + time per inner iteration.
+// The 4-wave candidates (half-size tiles) run two workgroups per CU: one's load/store phase hides
+// behind the other's arithmetic (3.3 us exposed per 4096-pixel tile instead of 14.4 us per 8192) and
+// the 4-wave barriers cost less (1.2 us per iteration instead of 2.63 / 2).
+double tile_launch_us(int cfg) { return kCfgs[cfg].NW == 8 ? 14.4 : 3.3; }
+double tile_iter_us(int cfg)
+{
+    const double t = kCfgs[cfg].NW == 8 ? 2.63 : 1.2;
+    return kCfgs[cfg].LX >= 32 ? t : 1.1 * t;  // 3- and 4-fold waves: a little slower
+}
+// A launch cannot beat the HBM stream of its tiles: ~5.2 TB/s measured = 20.3 kB per us per CU.
+double tile_hbm_us(int TW, int TH, int HX, int K) { return ((double)TW * TH * 40.0 + (double)(TW - 2 * HX) * (TH - 2 * K) * 24.0) / 20300.0; }
+double tile_cost_us(int cfg, int HX, int K)
+{
+    const int TW = kCfgs[cfg].LX * kCfgs[cfg].R, TH = kCfgs[cfg].NW * (64 / kCfgs[cfg].LX) * kCfgs[cfg].C;
+    const double c = tile_launch_us(cfg) + tile_iter_us(cfg) * K, m = tile_hbm_us(TW, TH, HX, K < TH / 2 ? K : 0);
+    return c > m ? c : m;
+}
 
 int tiles_1d(int n, int T, int halo)
 {
@@ -625,12 +643,14 @@ int tiles_1d(int n, int T, int halo)
     return va_cdiv(n - 2 * halo, T - 2 * halo);
 }
 
-// Pick the candidate with the fewest pixel slots for this level and K.
-TilePick pick_tiles(int w, int h, int K)
+// Pick the candidate with the lowest modelled cost per iteration for this level and K.
+TilePick pick_tiles(int w, int h, int K, unsigned mask)
 {
+    if (!mask) mask = (1u << kNumCfgs) - 1;
     TilePick best{};
     double best_cost = 1e300;
-    for (int i = 0; i < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++i) {
+    for (int i = 0; i < kNumCfgs; ++i) {
+        if (!((mask >> i) & 1)) continue;
         const int R = kCfgs[i].R, TW = kCfgs[i].LX * R, TH = kCfgs[i].NW * (64 / kCfgs[i].LX) * kCfgs[i].C;
         int k = K;
         if (h > TH && 2 * k >= TH) k = (TH - 1) / 2 > 0 ? (TH - 1) / 2 : 1;
@@ -641,32 +661,30 @@ TilePick pick_tiles(int w, int h, int K)
             if (2 * HX >= TW) continue;
         }
         const int ntx = tiles_1d(w, TW, HX), nty = tiles_1d(h, TH, k);
-        // measured on MI355X (tools/bench_tvl1_levels.py): a workgroup (one tile) costs ~14 us of exposed
-        // HBM round trip per launch plus ~2.9 us per inner iteration (3.2 us for the 3- and 4-fold
-        // waves); cost per iteration of this level:
-        const double cost = (double)ntx * nty * (kTileLaunchUs / k + tile_iter_us(kCfgs[i].LX));
+        const double cost = (double)ntx * nty * tile_cost_us(i, HX, k) / k;
         if (cost < best_cost) {
             best_cost = cost;
             best = TilePick{i, ntx, nty, HX, k};
         }
     }
+    if (best_cost == 1e300) return pick_tiles(w, h, K, 0u);  // no allowed candidate fits this halo: allow all
     return best;
 }
 
 // block_iters = 0: the depth K that minimises the modelled time of one warp's `iters` iterations
 // (full launches of K plus one shorter launch for the remainder).
-TilePick pick_tiles_auto(int w, int h, int iters)
+TilePick pick_tiles_auto(int w, int h, int iters, unsigned mask)
 {
     TilePick best{};
     double best_cost = 1e300;
     for (int K = 1; K <= 31 && K <= iters; ++K) {
-        const TilePick tp = pick_tiles(w, h, K);
+        const TilePick tp = pick_tiles(w, h, K, mask);
         if (tp.K != K) continue;
         const int full = iters / K, rem = iters - full * K;
-        double cost = (double)full * tp.ntx * tp.nty * (kTileLaunchUs + tile_iter_us(kCfgs[tp.cfg].LX) * K);
+        double cost = (double)full * tp.ntx * tp.nty * tile_cost_us(tp.cfg, tp.HX, K);
         if (rem) {
-            const TilePick tr = pick_tiles(w, h, rem);
-            cost += (double)tr.ntx * tr.nty * (kTileLaunchUs + tile_iter_us(kCfgs[tr.cfg].LX) * tr.K) * ((double)rem / tr.K);
+            const TilePick tr = pick_tiles(w, h, rem, mask);
+            cost += (double)tr.ntx * tr.nty * tile_cost_us(tr.cfg, tr.HX, tr.K) * ((double)rem / tr.K);
         }
         if (cost < best_cost) {
             best_cost = cost;
@@ -681,10 +699,14 @@ void launch_iter(const TilePick& tp, const IterArgs& a, int npairs, hipStream_t 
 {
     const dim3 grid(tp.ntx * tp.nty, npairs);
     switch (tp.cfg) {
-        case 0: k_iter_tile<2, 4, 8, 64, EPS, FAST><<<grid, 512, 0, st>>>(a); break;   // 256 x 32 tile
-        case 1: k_iter_tile<2, 4, 8, 32, EPS, FAST><<<grid, 512, 0, st>>>(a); break;   // 128 x 64 (2 row groups per wave)
-        case 2: k_iter_tile<2, 4, 8, 21, EPS, FAST><<<grid, 512, 0, st>>>(a); break;   // 84 x 96 (3 row groups, lane 63 idle)
-        default: k_iter_tile<2, 4, 8, 16, EPS, FAST><<<grid, 512, 0, st>>>(a); break;  // 64 x 128 (4 row groups)
+        case 0: k_iter_tile<2, 4, 8, 64, EPS, FAST><<<grid, 512, 0, st>>>(a); break;  // 256 x 32 tile
+        case 1: k_iter_tile<2, 4, 8, 32, EPS, FAST><<<grid, 512, 0, st>>>(a); break;  // 128 x 64 (2 row groups per wave)
+        case 2: k_iter_tile<2, 4, 8, 21, EPS, FAST><<<grid, 512, 0, st>>>(a); break;  // 84 x 96 (3 row groups, lane 63 idle)
+        case 3: k_iter_tile<2, 4, 8, 16, EPS, FAST><<<grid, 512, 0, st>>>(a); break;  // 64 x 128 (4 row groups)
+        case 4: k_iter_tile<2, 4, 4, 64, EPS, FAST><<<grid, 256, 0, st>>>(a); break;  // 256 x 16, two workgroups per CU
+        case 5: k_iter_tile<2, 4, 4, 32, EPS, FAST><<<grid, 256, 0, st>>>(a); break;  // 128 x 32
+        case 6: k_iter_tile<2, 4, 4, 21, EPS, FAST><<<grid, 256, 0, st>>>(a); break;  // 84 x 48
+        default: k_iter_tile<2, 4, 4, 16, EPS, FAST><<<grid, 256, 0, st>>>(a); break; // 64 x 64
     }
 }
 
@@ -721,6 +743,7 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
     VA_CHECK_ARG(p->tau > 0.0f && p->lambda > 0.0f && p->theta > 0.0f, "va_tvl1: tau, lambda, theta must be > 0");
     VA_CHECK_ARG(p->block_iters >= 0 && p->block_iters <= 64, "va_tvl1: block_iters must be in [0,64]");
     VA_CHECK_ARG(p->fast_math == 0 || p->fast_math == 1, "va_tvl1: fast_math must be 0 or 1");
+    VA_CHECK_ARG(p->tile_mask >= 0 && p->tile_mask < (1 << kNumCfgs), "va_tvl1: tile_mask must be in [0, %d]", (1 << kNumCfgs) - 1);
     VA_CHECK_ARG(p->tau / p->theta <= 1000.0f && p->lambda * p->theta <= 1000.0f, "va_tvl1: tau/theta and lambda*theta must be <= 1000");
     return VA_OK;
 }
@@ -777,8 +800,8 @@ va_prof_span prof_get(va_ctx* ctx)
         s = ctx->prof_pool.back();
         ctx->prof_pool.pop_back();
     } else {
-        hipEventCreate(&s.beg);
-        hipEventCreate(&s.end);
+        (void)hipEventCreate(&s.beg);
+        (void)hipEventCreate(&s.end);
     }
     return s;
 }
@@ -798,6 +821,7 @@ extern "C" void va_tvl1_default_params(va_tvl1_params* p)
     p->scale_step = 0.8f;
     p->block_iters = 0;
     p->fast_math = 0;
+    p->tile_mask = 0;
 }
 
 extern "C" int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* hs)
@@ -879,7 +903,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
     for (int s = sc; s >= 0; --s) {
         const int lw = P.ws[s], lh = P.hs[s], lp = P.pitch[s];
         const size_t plane = P.plane[s];
-        const TilePick tp = K0 > 0 ? pick_tiles(lw, lh, K0) : pick_tiles_auto(lw, lh, p->iters);
+        const TilePick tp = K0 > 0 ? pick_tiles(lw, lh, K0, (unsigned)p->tile_mask) : pick_tiles_auto(lw, lh, p->iters, (unsigned)p->tile_mask);
         const dim3 gpx(va_cdiv(lw * lh, TPB), P.NP);
         for (int wp = 0; wp < p->warps; ++wp) {
             k_warp<<<gpx, TPB, 0, st>>>(pyr[s], plane, lw, lh, lp, P.F, state[0], state[1], eps ? sel : nullptr, cur,
@@ -916,7 +940,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
             for (int it = 0; it < p->iters;) {
                 // the tile grid depends on the halo depth: a shorter last launch gets its own grid
                 const int k = (p->iters - it) < tp.K ? (p->iters - it) : tp.K;
-                const TilePick tk = (k == tp.K) ? tp : pick_tiles(lw, lh, k);
+                const TilePick tk = (k == tp.K) ? tp : pick_tiles(lw, lh, k, (unsigned)p->tile_mask);
                 a.ntx = tk.ntx;
                 a.nty = tk.nty;
                 a.HX = tk.HX;

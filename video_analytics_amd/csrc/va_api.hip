@@ -44,13 +44,13 @@ extern "C" void va_ctx_destroy(va_ctx* ctx)
 {
     if (!ctx) return;
     for (va_prof_span& s : ctx->prof_spans) {
-        hipEventDestroy(s.beg);
-        hipEventDestroy(s.end);
+        (void)hipEventDestroy(s.beg);
+        (void)hipEventDestroy(s.end);
     }
     for (va_prof_span& s : ctx->prof_pool) {
-        hipEventDestroy(s.beg);
-        hipEventDestroy(s.end);
+        (void)hipEventDestroy(s.beg);
+        (void)hipEventDestroy(s.end);
     }
-    if (ctx->prof_ref) hipEventDestroy(ctx->prof_ref);
+    if (ctx->prof_ref) (void)hipEventDestroy(ctx->prof_ref);
     delete ctx;
 }
