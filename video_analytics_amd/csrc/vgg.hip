@@ -900,16 +900,16 @@ extern "C" void va_vgg16_destroy(va_vgg16* m)
 {
     if (!m) return;
     for (int i = 0; i < 13; ++i) {
-        if (m->conv[i].wp) hipFree(m->conv[i].wp);
-        if (m->conv[i].wp_bf) hipFree(m->conv[i].wp_bf);
-        if (m->conv[i].bias) hipFree(m->conv[i].bias);
+        if (m->conv[i].wp) (void)hipFree(m->conv[i].wp);
+        if (m->conv[i].wp_bf) (void)hipFree(m->conv[i].wp_bf);
+        if (m->conv[i].bias) (void)hipFree(m->conv[i].bias);
     }
     for (int i = 0; i < 4; ++i) {
-        if (m->fcw[i]) hipFree(m->fcw[i]);
-        if (m->fcb[i]) hipFree(m->fcb[i]);
+        if (m->fcw[i]) (void)hipFree(m->fcw[i]);
+        if (m->fcb[i]) (void)hipFree(m->fcb[i]);
     }
-    if (m->in_mean) hipFree(m->in_mean);
-    if (m->in_std) hipFree(m->in_std);
+    if (m->in_mean) (void)hipFree(m->in_mean);
+    if (m->in_std) (void)hipFree(m->in_std);
     delete m;
 }
 
