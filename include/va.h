@@ -20,6 +20,10 @@
  *                     Sheet03/utils.py:148-150.
  *   va_validate_batch the loss / argmax / correct-count lines of validate():
  *                     Sheet03/spatialModel.py:219-221.
+ *   va_meter_*        the per-video AverageMeter collation of validate():
+ *                     Sheet03/utils.py:154-171, Sheet03/spatialModel.py:223-228.
+ *   va_linear_svm_predict   LinearSVC.predict on the joined descriptors:
+ *                     Sheet03/combinedModel.py:38.
  *
  * Conventions
  *   - return 0 (VA_OK) or an error code; va_last_error() returns a thread-local message.
@@ -174,6 +178,34 @@ int va_selftest_exact_math(va_ctx* ctx, float lo, float hi, unsigned long long* 
  */
 int va_tvl1_profile_enable(va_ctx* ctx, int on);
 int va_tvl1_profile_read(va_ctx* ctx, double* out, int reset);
+
+/* ------------------------------------------------ video-level aggregation and fusion --- */
+
+/*
+ * The AverageMeter bank of validate() (Sheet03/utils.py:154-171, Sheet03/spatialModel.py:223-228) kept
+ * on the device: desc f32 [batch][dim] (the descriptors of one batch), slot i32 [batch] = index of each
+ * clip's video in the caller's video list (a negative slot skips the row: padding);
+ * sums f32 [n_slots][dim] += desc row, counts i32 [n_slots] += 1, rows applied in batch order (a video
+ * occurring twice in a batch gets both adds in that order: bit-identical to update() row by row).
+ * Replaces the per-batch device-to-host copy of the reference loop.
+ */
+int va_meter_update(va_ctx* ctx, const void* desc, const void* slot, int batch, int dim,
+                    void* sums, void* counts, int n_slots, void* stream);
+/* avg f32 [n_slots][dim] = sums / counts (AverageMeter.avg; 0 where counts == 0). */
+int va_meter_average(va_ctx* ctx, const void* sums, const void* counts, int n_slots, int dim,
+                     void* avg, void* stream);
+
+/*
+ * LinearSVC.predict of the fusion step (Sheet03/combinedModel.py:38): x f64 [n][dim] (the joined
+ * descriptors of combineDescriptors, Sheet03/combinedModel.py:9-26), coef f64 [n_class_rows][dim],
+ * intercept f64 [n_class_rows] (sklearn's coef_ / intercept_; n_class_rows == 1 for a binary problem)
+ * -> scores f64 [n][n_class_rows] = x coef^T + intercept (sum over dim in ascending order, double
+ * multiply then add), pred i32 [n] = index into classes_: arg-max (first maximum), or score > 0 for
+ * the binary case.  Fitting the SVM stays on the CPU (liblinear).
+ */
+int va_linear_svm_predict(va_ctx* ctx, const void* x, int n, int dim, const void* coef,
+                          const void* intercept, int n_class_rows, void* scores, void* pred,
+                          void* stream);
 
 #ifdef __cplusplus
 }

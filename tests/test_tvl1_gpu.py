@@ -64,6 +64,26 @@ def test_every_register_tile_candidate_bit_exact(oracle_tvl1, bit):
     assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("fill", [0xFF, 0x7F])
+def test_result_does_not_depend_on_what_the_workspace_held(oracle_tvl1, fill):
+    # the caller owns the workspace and may hand over anything: NaN (0xFFFFFFFF) and huge (0x7F7F7F7F)
+    # bit patterns everywhere, widths that leave pitch padding on every level
+    from video_analytics_amd import flow as vflow
+    gray = _frames(2, 3, 57, 131, seed=31)
+    kw = dict(epsilon=0.0, iters=21, warps=2, nscales=3, block_iters=4)
+    ref = oracle_tvl1.tvl1_flow(gray.numpy(), oracle_tvl1.default_params(epsilon=0.0, iters=21, warps=2, nscales=3), nthreads=8)
+    vflow.tvl1_flow(gray.cuda(), **kw)  # sizes the cached workspace
+    for t in vflow._ws_cache.values():
+        t.fill_(fill)
+    out = vflow.tvl1_flow(gray.cuda(), **kw).cpu().numpy()
+    assert np.array_equal(out, ref), "max abs diff %g" % np.nanmax(np.abs(out - ref))
+    for t in vflow._ws_cache.values():
+        t.fill_(fill)
+    out = vflow.tvl1_flow(gray.cuda(), epsilon=0.02, iters=40, warps=1, nscales=3).cpu().numpy()
+    ref = oracle_tvl1.tvl1_flow(gray.numpy(), oracle_tvl1.default_params(epsilon=0.02, iters=40, warps=1, nscales=3), nthreads=8)
+    assert np.array_equal(out, ref)
+
+
 @pytest.mark.parametrize("H,W", [(16, 16), (17, 19), (33, 130), (65, 257)])
 def test_minimum_and_ragged_sizes_bit_exact(oracle_tvl1, H, W):
     # the smallest accepted frame (16x16: a single pyramid level) and widths/heights that are not

@@ -32,6 +32,22 @@ def test_copy_first_layer_matches_reference_rule(weights3):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_result_does_not_depend_on_what_the_workspace_held(weights3, dtype):
+    # the caller owns the workspace: NaN bit patterns everywhere must not leak into the result
+    from video_analytics_amd import vgg
+    w = weights3
+    x = _inputs(3, 3, seed=8).cuda()
+    m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256, dtype=dtype)
+    a = [t.clone() for t in m.forward(x, want_feat=True)]
+    for t in vgg._ws_cache.values():
+        t.fill_(0xFF)
+    b = m.forward(x, want_feat=True)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    m.close()
+
+
 @pytest.mark.parametrize("B", [1, 3])
 def test_spatial_stream_matches_oracle(weights3, B):
     from oracle import vgg_oracle

@@ -19,6 +19,7 @@ EXPORTS = [
     "va_copy_first_layer", "va_validate_batch",
     "va_tvl1_default_params", "va_tvl1_pyramid_sizes", "va_tvl1_workspace_bytes", "va_tvl1_flow",
     "va_flow_to_stack", "va_selftest_exact_math", "va_tvl1_profile_enable", "va_tvl1_profile_read",
+    "va_meter_update", "va_meter_average", "va_linear_svm_predict",
 ]
 
 
@@ -98,6 +99,12 @@ def lib():
     L.va_tvl1_profile_enable.restype = ci
     L.va_tvl1_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ci]
     L.va_tvl1_profile_read.restype = ci
+    L.va_meter_update.argtypes = [vp, vp, vp, ci, ci, vp, vp, ci, vp]
+    L.va_meter_update.restype = ci
+    L.va_meter_average.argtypes = [vp, vp, vp, ci, ci, vp, vp]
+    L.va_meter_average.restype = ci
+    L.va_linear_svm_predict.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp, vp, vp]
+    L.va_linear_svm_predict.restype = ci
     _lib = L
     return L
 

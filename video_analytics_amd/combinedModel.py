@@ -28,9 +28,11 @@ def combineDescriptors(spatialCsv, temporalCsv):
 
 
 def linearSvmPredict(descriptors, coef, intercept, classes):
-    """``LinearSVC.predict``: classes[argmax(X coef^T + intercept)] (one-vs-rest, >2 classes)."""
-    scores = np.asarray(descriptors, dtype=np.float64) @ np.asarray(coef, dtype=np.float64).T + np.asarray(intercept)
-    return np.asarray(classes)[scores.argmax(axis=1)]
+    """``LinearSVC.predict`` (Sheet03/combinedModel.py:38) on the GPU: classes[argmax(X coef^T + intercept)]
+    (one-vs-rest; a single coefficient row is the binary case).  ``coef`` / ``intercept`` / ``classes``
+    are a fitted ``LinearSVC``'s ``coef_`` / ``intercept_`` / ``classes_`` (fitting stays on the CPU)."""
+    from . import fusion
+    return fusion.linear_svm_predict(descriptors, coef, intercept, classes)
 
 
 def accuracy(preds, labels):

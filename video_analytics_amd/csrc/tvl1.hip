@@ -222,21 +222,35 @@ __global__ void k_upsample(const float* __restrict__ stA, const float* __restric
 }
 
 // S4: start of a level: u from tmp, p = 0, everything in ping-pong buffer 0.
+// Also zeroes the pitch padding (columns w .. pitch-1) of the state: k_iter_tile loads whole 4-pixel
+// runs, and although no padding value can reach a valid pixel (the forward differences at x = w-1
+// are multiplied by 0), a NaN/Inf bit pattern left there by an earlier owner of the workspace would
+// (NaN * 0 = NaN).  Everything the kernels themselves write is finite.
 __global__ void k_level_init(const float* __restrict__ tmp, float* __restrict__ st0, int w, int h, int pitch, size_t plane)
 {
     const int pair = blockIdx.y;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= w * h) return;
-    const int y = idx / w, x = idx - y * w;
+    if (idx >= pitch * h) return;
+    const int y = idx / pitch, x = idx - y * pitch;
     const size_t o = (size_t)y * pitch + x;
     const float* t = tmp + (size_t)pair * 2 * plane;
     float* dst = st0 + (size_t)pair * kNF_STATE * plane;
-    dst[o] = t[o];
-    dst[plane + o] = t[plane + o];
+    dst[o] = x < w ? t[o] : 0.0f;
+    dst[plane + o] = x < w ? t[plane + o] : 0.0f;
     dst[2 * plane + o] = 0.0f;
     dst[3 * plane + o] = 0.0f;
     dst[4 * plane + o] = 0.0f;
     dst[5 * plane + o] = 0.0f;
+}
+
+// Zero the pitch padding of the nf planes of every pair (the per-warp constants: k_warp writes x < w only).
+__global__ void k_zero_pad(float* __restrict__ buf, int nf, int w, int h, int pitch, size_t plane)
+{
+    const int pair = blockIdx.y, pw = pitch - w;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= pw * h * nf) return;
+    const int f = idx / (pw * h), r = idx - f * pw * h, y = r / pw, x = w + r - y * pw;
+    buf[((size_t)pair * nf + f) * plane + (size_t)y * pitch + x] = 0.0f;
 }
 
 __global__ void k_flow_out(const float* __restrict__ stA, const float* __restrict__ stB, const int* __restrict__ sel,
@@ -905,6 +919,10 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
         const size_t plane = P.plane[s];
         const TilePick tp = K0 > 0 ? pick_tiles(lw, lh, K0, (unsigned)p->tile_mask) : pick_tiles_auto(lw, lh, p->iters, (unsigned)p->tile_mask);
         const dim3 gpx(va_cdiv(lw * lh, TPB), P.NP);
+        if (lp != lw) {
+            k_zero_pad<<<dim3(va_cdiv((lp - lw) * lh * kNF_RO, TPB), P.NP), TPB, 0, st>>>(ro, kNF_RO, lw, lh, lp, plane);
+            VA_LAUNCH_CHECK();
+        }
         for (int wp = 0; wp < p->warps; ++wp) {
             k_warp<<<gpx, TPB, 0, st>>>(pyr[s], plane, lw, lh, lp, P.F, state[0], state[1], eps ? sel : nullptr, cur,
                                          eps ? base : nullptr, ro);
@@ -972,7 +990,8 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
             const dim3 g(va_cdiv(P.ws[s - 1] * P.hs[s - 1], TPB), P.NP);
             k_upsample<<<g, TPB, 0, st>>>(state[0], state[1], eps ? sel : nullptr, cur, lw, lh, lp, plane, ro, P.ws[s - 1],
                                            P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1], 1.0f / p->scale_step);
-            k_level_init<<<g, TPB, 0, st>>>(ro, state[0], P.ws[s - 1], P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1]);
+            const dim3 gi(va_cdiv(P.pitch[s - 1] * P.hs[s - 1], TPB), P.NP);
+            k_level_init<<<gi, TPB, 0, st>>>(ro, state[0], P.ws[s - 1], P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1]);
             VA_LAUNCH_CHECK();
             cur = 0;
             if (eps) VA_HIP(hipMemsetAsync(sel, 0, (size_t)P.NP * sizeof(int), st));

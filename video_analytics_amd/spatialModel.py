@@ -15,7 +15,7 @@ import torch
 from PIL import Image
 from torch.utils.data import Dataset
 
-from . import synth, vgg
+from . import fusion, synth, vgg
 from .parameters import *  # noqa: F401,F403
 from .parameters import (FRAME_EXTN, NORM_MEANS_TF, NORM_STDS_TF, SPATIAL_TEST_CSV_LOC, VIDEO_INPUT_FRAME_COUNT)
 from .utils import AverageMeter, ToTensor, saveVideoDescriptors, spatialFrameIndex, videoInfo
@@ -103,6 +103,7 @@ class SpatialNetwork(object):
         self.classify = self.model.classify
         self.trainDict = {}
         self.testDict = {}
+        self.testMeters = fusion.DescriptorMeters(descriptorDim, self.device)  # persists across epochs (quirk 7)
 
     def _build(self, weights):
         return vgg.Vgg16Stream(weights["conv_w"], weights["conv_b"], weights["fc_w"], weights["fc_b"],
@@ -119,15 +120,13 @@ class SpatialNetwork(object):
             op = self.features(ip)
             featureVectors, op = self.classify(op)
             pending.append(vgg.validate_batch(op, labels))  # [mean CE, n correct] on the device, no sync
-            fv = featureVectors.cpu()
-            for i in range(len(fv)):
-                if videoNames[i] not in self.testDict:
-                    self.testDict[videoNames[i]] = (AverageMeter(), labels[i])
-                self.testDict[videoNames[i]][0].update(fv[i])
+            # per-video running means (Sheet03/spatialModel.py:223-228) accumulate in HBM: no copy per batch
+            self.testMeters.update(featureVectors, videoNames, labels)
         for t in pending:
             v = t.cpu()
             loss = loss + v[0]
             correct += int(v[1].item())
+        self.testDict = self.testMeters.as_dict()
         print("Validation for epoch %d: total = %d, correct = %d, loss = %f"
               % (self.epoch, self.totalTest, correct, float(loss)))
         return (correct / self.totalTest), loss
