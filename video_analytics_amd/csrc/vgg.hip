@@ -324,7 +324,6 @@ __global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kBfBK = 64;      // channels per K step
-constexpr int kBfLds = 72;     // bf16 elements per LDS row (144 B)
 
 // OIHW f32 [Cout][Cin][3][3] -> bf16 [Cout][9][cpad]
 __global__ void k_pack_conv_w_bf16(const float* __restrict__ w, __bf16* __restrict__ wp, int Cout, int Cin, int cpad)
@@ -339,23 +338,38 @@ __global__ void k_pack_conv_w_bf16(const float* __restrict__ w, __bf16* __restri
 }
 
 struct ConvArgsBf {
-    const __bf16* in;   // NHWC [B][H][W][Cin], Cin % 64 == 0
-    const __bf16* wp;   // [Cout][9*Cin]
-    const float* bias;  // [Cout]
-    void* out;          // NHWC bf16 (or f32 when OUT_F32), pooled when POOL
+    const __bf16* in;     // NHWC [B][H][W][Cin], Cin % 64 == 0
+    const __bf16* wp;     // [Cout][9*Cin]
+    const float* bias;    // [Cout]
+    void* out;            // NHWC bf16 (or f32 when OUT_F32), pooled when POOL
+    const __bf16* zeros;  // >= 16 zero bytes: the source of every out-of-image tap
     int B, H, W, Cin, Cout;
     int lgTW, lgTH, TB;
     int tiles_x, tiles_y, tiles_n;
 };
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
 // 128 pixels x (NT*64) channels per workgroup of 4 waves (2 x 2), wave tile 64 x (NT*32).
+//
+// Staging: LDS-DMA (global_load_lds_dwordx4), no staging registers and no ds_write pass.  One wave
+// instruction fills 1 KB = 8 rows x 128 B of the tile; the LDS image is lane-linear, so the bank swizzle
+// sits on the SOURCE side: lane (row r, slot p) fetches 16-byte chunk c = p ^ ((r >> 1) & 7) of its row's
+// 128-byte line (still one whole line per 8 lanes), and a fragment read of chunk c of row m goes to slot
+// c ^ ((m >> 1) & 7): the 16 lanes of a ds_read_b128 group (16 consecutive rows, same c) then cover the
+// 16 slots of the 256-byte bank row exactly once.  Out-of-image taps read a zero line.  One LDS buffer
+// (32 KB at NT = 2), two barriers per K step, <= 128 VGPRs: four workgroups per CU hide each other's
+// load latency (measured: a second LDS buffer with the next step's DMA in flight, at two workgroups per
+// CU, is 8 % slower).
 template <int NT, bool POOL, bool OUT_F32>
-__global__ void __launch_bounds__(256) k_conv3x3_mfma_bf16(ConvArgsBf a)
+__global__ void __launch_bounds__(256, 4) k_conv3x3_mfma_bf16(ConvArgsBf a)
 {
     constexpr int BM = 128, BN = NT * 64, MT = 2;
-    constexpr int ROWS_PER_PASS = 32, A_PASSES = BM / ROWS_PER_PASS, B_PASSES = BN / ROWS_PER_PASS;
-    __shared__ __attribute__((aligned(16))) __bf16 sA[2][BM * kBfLds];
-    __shared__ __attribute__((aligned(16))) __bf16 sB[2][BN * kBfLds];
+    constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;  // LDS-DMA instructions per wave and K step (8 rows each)
+    __shared__ __attribute__((aligned(1024))) __bf16 smem[(BM + BN) * kBfBK];
+    __bf16* const sA = smem;
+    __bf16* const sB = smem + BM * kBfBK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -370,24 +384,29 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma_bf16(ConvArgsBf a)
     const int H = a.H, W = a.W, Cin = a.Cin;
     const int X0 = tile_x << a.lgTW, Y0 = tile_y << a.lgTH, B0 = tile_b * a.TB;
 
-    // loader role: 16-byte chunk q (8 channels) of rows (tid>>3) + 32*i
-    const int q = tid & 7, rowbase = tid >> 3;
-    int ax[A_PASSES], ay[A_PASSES];
-    long apix[A_PASSES];
-    bool aok[A_PASSES];
+    // loader role: row (lane >> 3) of the 8-row group, slot (lane & 7)
+    const int lrow = lane >> 3, lslot = lane & 7;
+    int ax[A_INSTR], ay[A_INSTR];
+    long apix[A_INSTR];
+    bool aok[A_INSTR];
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int row = (wave * A_INSTR + i) * 8 + lrow;
+        const int c = lslot ^ ((row >> 1) & 7);
         int xl, yl, bl;
-        brick_coords(rowbase + ROWS_PER_PASS * i, a.lgTW, a.lgTH, xl, yl, bl);
+        brick_coords(row, a.lgTW, a.lgTH, xl, yl, bl);
         ax[i] = X0 + xl;
         ay[i] = Y0 + yl;
         const int b = B0 + bl;
         aok[i] = b < a.B && ax[i] < W && ay[i] < H;
-        apix[i] = (((long)b * H + ay[i]) * W + ax[i]) * Cin + 8 * q;
+        apix[i] = (((long)b * H + ay[i]) * W + ax[i]) * Cin + 8 * c;
     }
-    const __bf16* wrow[B_PASSES];
+    const __bf16* wrow[B_INSTR];
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) wrow[i] = a.wp + (size_t)(n0 + rowbase + ROWS_PER_PASS * i) * 9 * Cin + 8 * q;
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int row = (wave * B_INSTR + i) * 8 + lrow;
+        wrow[i] = a.wp + (size_t)(n0 + row) * 9 * Cin + 8 * (lslot ^ ((row >> 1) & 7));
+    }
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -399,62 +418,49 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma_bf16(ConvArgsBf a)
 
     const int cchunks = Cin / kBfBK;
     const int T = 9 * cchunks;
-    u32x4 ra[A_PASSES], rb[B_PASSES];
-#define VA_CONV_GLOAD(t_)                                                                                       \
-    {                                                                                                           \
-        const int kp_ = (t_) / cchunks, c0_ = ((t_)-kp_ * cchunks) * kBfBK;                                     \
-        const int ky_ = kp_ / 3 - 1, kx_ = kp_ % 3 - 1;                                                         \
-        static_for<A_PASSES>([&](auto I) {                                                                      \
-            constexpr int i = decltype(I)::value;                                                               \
-            const int yy_ = ay[i] + ky_, xx_ = ax[i] + kx_;                                                     \
-            const bool ok_ = aok[i] && yy_ >= 0 && yy_ < H && xx_ >= 0 && xx_ < W;                              \
-            ra[i] = ok_ ? *reinterpret_cast<const u32x4*>(a.in + apix[i] + ((long)ky_ * W + kx_) * Cin + c0_)   \
-                        : u32x4{0u, 0u, 0u, 0u};                                                                \
-        });                                                                                                     \
-        static_for<B_PASSES>([&](auto I) {                                                                      \
-            constexpr int i = decltype(I)::value;                                                               \
-            rb[i] = *reinterpret_cast<const u32x4*>(wrow[i] + (size_t)kp_ * Cin + c0_);                         \
-        });                                                                                                     \
-    }
-#define VA_CONV_LSTORE(buf_)                                                                                    \
-    {                                                                                                           \
-        static_for<A_PASSES>([&](auto I) {                                                                      \
-            constexpr int i = decltype(I)::value;                                                               \
-            *reinterpret_cast<u32x4*>(&sA[buf_][(rowbase + ROWS_PER_PASS * i) * kBfLds + 8 * q]) = ra[i];        \
-        });                                                                                                     \
-        static_for<B_PASSES>([&](auto I) {                                                                      \
-            constexpr int i = decltype(I)::value;                                                               \
-            *reinterpret_cast<u32x4*>(&sB[buf_][(rowbase + ROWS_PER_PASS * i) * kBfLds + 8 * q]) = rb[i];        \
-        });                                                                                                     \
-    }
-
-    VA_CONV_GLOAD(0)
-    VA_CONV_LSTORE(0)
-    __syncthreads();
     const int r31 = lane & 31, hh = lane >> 5;
+    const int fsw = (r31 >> 1) & 7;  // fragment rows are (multiple of 32) + r31
+    int kp = 0, c0 = 0;
     for (int t = 0; t < T; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < T) VA_CONV_GLOAD(t + 1)
+        const int ky = kp / 3 - 1, kx = kp % 3 - 1;
+        const long tap = ((long)ky * W + kx) * Cin + c0;
+        static_for<A_INSTR>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const int yy = ay[i] + ky, xx = ax[i] + kx;
+            const bool ok = aok[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const __bf16* src = ok ? a.in + apix[i] + tap : a.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sA + (wave * A_INSTR + i) * 8 * kBfBK), 16, 0, 0);
+        });
+        static_for<B_INSTR>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wrow[i] + (size_t)kp * Cin + c0),
+                                             (lds_ptr_t)(sB + (wave * B_INSTR + i) * 8 * kBfBK), 16, 0, 0);
+        });
+        c0 += kBfBK;
+        if (c0 == Cin) {
+            c0 = 0;
+            ++kp;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < kBfBK / 16; ++ks) {
             bf16x8 fa[MT], fb[NT];
+            const int slot = ((2 * ks + hh) ^ fsw) * 8;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                fa[mt] = *reinterpret_cast<const bf16x8*>(&sA[buf][((wm * MT + mt) * 32 + r31) * kBfLds + 16 * ks + 8 * hh]);
+                fa[mt] = *reinterpret_cast<const bf16x8*>(&sA[((wm * MT + mt) * 32 + r31) * kBfBK + slot]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                fb[nt] = *reinterpret_cast<const bf16x8*>(&sB[buf][((wn * NT + nt) * 32 + r31) * kBfLds + 16 * ks + 8 * hh]);
+                fb[nt] = *reinterpret_cast<const bf16x8*>(&sB[((wn * NT + nt) * 32 + r31) * kBfBK + slot]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
         }
-        if (t + 1 < T) VA_CONV_LSTORE(buf ^ 1)
-        __syncthreads();
+        __syncthreads();  // every wave has read the tile before the next DMA overwrites it
     }
-#undef VA_CONV_GLOAD
-#undef VA_CONV_LSTORE
 
     // epilogue: bias + ReLU (+ 2x2 max-pool over the 4 registers reg&3 of a lane), fp32 math, bf16/f32 store
 #pragma unroll
@@ -645,6 +651,7 @@ struct va_vgg16 {
     int fc_in[4], fc_out[4];
     float* in_mean;  // device [c_in] or NULL
     float* in_std;
+    __bf16* zeros;   // 256 zero bytes (VA_DTYPE_BF16: source of the out-of-image taps)
 };
 
 namespace {
@@ -700,10 +707,11 @@ int launch_conv(const ConvLayer& L, const float* in, float* out, int B, hipStrea
     return VA_OK;
 }
 
-int launch_conv_bf16(const ConvLayer& L, const __bf16* in, void* out, bool out_f32, int B, hipStream_t st)
+int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, const __bf16* in, void* out, bool out_f32, int B, hipStream_t st)
 {
     ConvArgsBf a{};
     a.in = in;
+    a.zeros = zeros;
     a.wp = L.wp_bf;
     a.bias = L.bias;
     a.out = out;
@@ -844,6 +852,12 @@ extern "C" int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_di
     int hw = 224, cin = c_in, cin_pad = m->c_in_pad;
     int rc = VA_OK;
     auto fail = [&](int code) { va_vgg16_destroy(m); return code; };
+    if (dtype == VA_DTYPE_BF16) {
+        if (hipMalloc(&m->zeros, 256) != hipSuccess || hipMemsetAsync(m->zeros, 0, 256, st) != hipSuccess) {
+            va_set_error("va_vgg16_create: hipMalloc failed for the zero line");
+            return fail(VA_ERR_HIP);
+        }
+    }
     for (int i = 0; i < 13; ++i) {
         ConvLayer& L = m->conv[i];
         L.cin = cin;
@@ -908,6 +922,7 @@ extern "C" void va_vgg16_destroy(va_vgg16* m)
         if (m->fcw[i]) (void)hipFree(m->fcw[i]);
         if (m->fcb[i]) (void)hipFree(m->fcb[i]);
     }
+    if (m->zeros) (void)hipFree(m->zeros);
     if (m->in_mean) (void)hipFree(m->in_mean);
     if (m->in_std) (void)hipFree(m->in_std);
     delete m;
@@ -948,7 +963,7 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
             k_nchw_to_nhwc_pad<float, __bf16><<<pgrid, 256, 0, st>>>((const float*)x, (__bf16*)act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
         VA_LAUNCH_CHECK();
         for (int i = 0; i < 13; ++i) {
-            if (int rc = launch_conv_bf16(m->conv[i], (const __bf16*)act[cur], act[cur ^ 1], i == 12, B, st)) return rc;
+            if (int rc = launch_conv_bf16(m->conv[i], m->zeros, (const __bf16*)act[cur], act[cur ^ 1], i == 12, B, st)) return rc;
             cur ^= 1;
         }
     } else {
