@@ -61,6 +61,37 @@ def forward(x, conv_w, conv_b, fc_w, fc_b, dtype=torch.float32):
     return feat, desc, logits
 
 
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def forward_bf16(x, conv_w, conv_b, fc_w, fc_b):
+    """The bf16 throughput configuration (BASELINE config 5) restated: conv inputs and weights rounded to
+    bf16 (round-to-nearest-even), exact products, fp32 accumulation / bias / ReLU / max-pool, activations
+    stored as bf16 between conv layers, the last conv output and the whole classifier in fp32.  Differs
+    from the HIP path only by the fp32 accumulation order (and the rare bf16 rounding flips it causes)."""
+    with torch.no_grad():
+        x = _bf16(x.to(torch.float32))
+        i = 0
+        n_conv = sum(1 for v in VGG16_CFG if v != "M")
+        for v in VGG16_CFG:
+            if v == "M":
+                x = F.max_pool2d(x, kernel_size=2, stride=2)
+                if i < n_conv:
+                    x = _bf16(x)
+            else:
+                x = F.relu(F.conv2d(x, _bf16(conv_w[i]), conv_b[i].to(torch.float32), padding=1))
+                i += 1
+                nxt_is_pool = True  # rounding happens once, after the pool when one follows
+                # find whether a pool follows this conv
+                k = [j for j, u in enumerate(VGG16_CFG) if u != "M"][i - 1]
+                if not (k + 1 < len(VGG16_CFG) and VGG16_CFG[k + 1] == "M"):
+                    x = _bf16(x)
+        feat = x
+        desc, logits = classifier(feat, [w.to(torch.float32) for w in fc_w], [b.to(torch.float32) for b in fc_b])
+    return feat, desc, logits
+
+
 def copy_first_layer(w_rgb, n_in):
     """Sheet03/temporalModel.py:155-161: avg over the 3 input channels, replicated n_in times."""
     avg = 0

@@ -22,6 +22,7 @@
 //     FC1's weight is repacked so that the NHWC feature map can be used without a transpose while
 //     keeping the reference's CHW-major flatten order c*49+h*7+w (Sheet03/spatialModel.py:213).
 #include "va_internal.h"
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -73,6 +74,48 @@ __global__ void __launch_bounds__(256) k_nchw_to_nhwc_pad(const TIN* __restrict_
     const int npx = HW - p0 < 64 ? HW - p0 : 64;
     TOUT* o = out + ((size_t)b * HW + p0) * cpad;
     for (int i = t; i < npx * cpad; i += 256) o[i] = (TOUT)tile[i / cpad][i % cpad];
+}
+
+// bf16 first layer (3*C <= 64): NCHW -> NHWC bf16 [B][HW][64] holding, for every pixel, the three horizontal
+// taps x-1, x, x+1 of all C channels (channel j = kx*C + c; zeros outside the image and for j >= 3*C).  The
+// 3x3 convolution of the first layer then needs 3 K steps (one per kernel row) instead of 9, on an input of
+// the same size as the plain 64-channel padding.
+template <typename TIN>
+__global__ void __launch_bounds__(256) k_nchw_to_nhwc_xcol(const TIN* __restrict__ x, __bf16* __restrict__ out, int B, int C, int W,
+                                                            int HW, const float* __restrict__ mean, const float* __restrict__ stdv)
+{
+    __shared__ float tile[66][21];  // pixels p0-1 .. p0+64, C <= 21
+    const int tiles_per_img = (HW + 63) / 64;
+    const int b = blockIdx.x / tiles_per_img, p0 = (blockIdx.x - b * tiles_per_img) * 64;
+    const int t = threadIdx.x;
+    for (int i = t; i < 66 * C; i += 256) {
+        const int c = i / 66, pl = i - c * 66, p = p0 + pl - 1;
+        float v = 0.0f;
+        if (p >= 0 && p < HW) {
+            const TIN raw = x[((size_t)b * C + c) * HW + p];
+            if constexpr (sizeof(TIN) == 1) v = ((float)raw / 255.0f - mean[c]) / stdv[c];
+            else v = (float)raw;
+        }
+        tile[pl][c] = v;
+    }
+    __syncthreads();
+    const int npx = HW - p0 < 64 ? HW - p0 : 64;
+    __bf16* o = out + ((size_t)b * HW + p0) * 64;
+    for (int i = t; i < npx * 64; i += 256) {
+        const int pl = i >> 6, j = i & 63, kx = j / C, c = j - kx * C;
+        const int xx = (p0 + pl) % W + kx - 1;
+        o[i] = (__bf16)((kx < 3 && xx >= 0 && xx < W) ? tile[pl + kx][c] : 0.0f);
+    }
+}
+
+// OIHW f32 [Cout][Cin][3][3] -> bf16 [Cout][3 (ky)][64]: element kx*Cin + ci of row ky (the layout above)
+__global__ void k_pack_conv_w_bf16_xcol(const float* __restrict__ w, __bf16* __restrict__ wp, int Cout, int Cin)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cout * 3 * 64) return;
+    const int j = idx & 63, ky = (idx >> 6) % 3, n = idx / 192;
+    const int kx = j / Cin, ci = j - kx * Cin;
+    wp[idx] = (__bf16)(kx < 3 ? w[((size_t)n * Cin + ci) * 9 + ky * 3 + kx] : 0.0f);
 }
 
 // OIHW [Cout][Cin][3][3] -> [Cout][9][cpad]
@@ -346,6 +389,7 @@ struct ConvArgsBf {
     int B, H, W, Cin, Cout;
     int lgTW, lgTH, TB;
     int tiles_x, tiles_y, tiles_n;
+    int taps_x;           // 3: 3x3 taps; 1: the x taps are folded into the channels (k_nchw_to_nhwc_xcol), 3 row taps
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -362,14 +406,17 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // (32 KB at NT = 2), two barriers per K step, <= 128 VGPRs: four workgroups per CU hide each other's
 // load latency (measured: a second LDS buffer with the next step's DMA in flight, at two workgroups per
 // CU, is 8 % slower).
-template <int NT, bool POOL, bool OUT_F32>
-__global__ void __launch_bounds__(256, 4) k_conv3x3_mfma_bf16(ConvArgsBf a)
+//
+// NBUF = 1: the scheme above.  NBUF >= 3: a ring of NBUF tiles with NBUF-1 K steps of DMA in flight (counted
+// s_waitcnt vmcnt, raw s_barrier, one barrier per step) for the layers that cannot put several workgroups on
+// every CU (14x14: 392 workgroups of 72 latency-bound steps).
+template <int NT, bool POOL, bool OUT_F32, int NBUF>
+__global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) k_conv3x3_mfma_bf16(ConvArgsBf a)
 {
     constexpr int BM = 128, BN = NT * 64, MT = 2;
     constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;  // LDS-DMA instructions per wave and K step (8 rows each)
-    __shared__ __attribute__((aligned(1024))) __bf16 smem[(BM + BN) * kBfBK];
-    __bf16* const sA = smem;
-    __bf16* const sB = smem + BM * kBfBK;
+    constexpr int TILE = (BM + BN) * kBfBK;  // bf16 elements of one K step's A and B tiles
+    __shared__ __attribute__((aligned(1024))) __bf16 smem[NBUF * TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -405,7 +452,7 @@ __global__ void __launch_bounds__(256, 4) k_conv3x3_mfma_bf16(ConvArgsBf a)
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
         const int row = (wave * B_INSTR + i) * 8 + lrow;
-        wrow[i] = a.wp + (size_t)(n0 + row) * 9 * Cin + 8 * (lslot ^ ((row >> 1) & 7));
+        wrow[i] = a.wp + (size_t)(n0 + row) * 3 * a.taps_x * Cin + 8 * (lslot ^ ((row >> 1) & 7));
     }
 
     f32x16 acc[MT][NT];
@@ -417,12 +464,15 @@ __global__ void __launch_bounds__(256, 4) k_conv3x3_mfma_bf16(ConvArgsBf a)
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
     const int cchunks = Cin / kBfBK;
-    const int T = 9 * cchunks;
+    const int T = 3 * a.taps_x * cchunks;
     const int r31 = lane & 31, hh = lane >> 5;
     const int fsw = (r31 >> 1) & 7;  // fragment rows are (multiple of 32) + r31
     int kp = 0, c0 = 0;
-    for (int t = 0; t < T; ++t) {
-        const int ky = kp / 3 - 1, kx = kp % 3 - 1;
+    // LDS-DMA of K step (kp, c0) into ring slot `buf`; advances (kp, c0)
+    auto stage = [&](int buf) {
+        __bf16* const sA = smem + buf * TILE;
+        __bf16* const sB = sA + BM * kBfBK;
+        const int ky = a.taps_x == 3 ? kp / 3 - 1 : kp - 1, kx = a.taps_x == 3 ? kp % 3 - 1 : 0;
         const long tap = ((long)ky * W + kx) * Cin + c0;
         static_for<A_INSTR>([&](auto I) {
             constexpr int i = decltype(I)::value;
@@ -441,8 +491,10 @@ __global__ void __launch_bounds__(256, 4) k_conv3x3_mfma_bf16(ConvArgsBf a)
             c0 = 0;
             ++kp;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    };
+    auto compute = [&](int buf) {
+        const __bf16* const sA = smem + buf * TILE;
+        const __bf16* const sB = sA + BM * kBfBK;
 #pragma unroll
         for (int ks = 0; ks < kBfBK / 16; ++ks) {
             bf16x8 fa[MT], fb[NT];
@@ -459,7 +511,38 @@ __global__ void __launch_bounds__(256, 4) k_conv3x3_mfma_bf16(ConvArgsBf a)
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
         }
-        __syncthreads();  // every wave has read the tile before the next DMA overwrites it
+    };
+    if constexpr (NBUF == 1) {
+        for (int t = 0; t < T; ++t) {
+            stage(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();  // every wave has read the tile before the next DMA overwrites it
+        }
+    } else {
+        constexpr int LOADS = A_INSTR + B_INSTR;  // this wave's DMA instructions per K step
+        // prologue: NBUF-1 steps in flight (T >= 3 >= NBUF-1 is not guaranteed for NBUF > 4: launch only NBUF <= 4)
+        for (int j = 0; j < NBUF - 1 && j < T; ++j) stage(j);
+        int slot = 0;
+        for (int t = 0; t < T; ++t) {
+            // wait until this wave's DMAs of step t have landed: steps t+1 .. t+NBUF-2 may stay in flight
+            if (t + NBUF - 2 < T) {
+                if constexpr ((NBUF - 2) * LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if constexpr ((NBUF - 2) * LOADS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if constexpr ((NBUF - 2) * LOADS == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if constexpr ((NBUF - 2) * LOADS == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // all waves: step t's tile is complete, and step t-1's reads are done, so its slot can be refilled
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + NBUF - 1 < T) stage(slot == 0 ? NBUF - 1 : slot - 1);
+            compute(slot);
+            slot = slot + 1 == NBUF ? 0 : slot + 1;
+        }
     }
 
     // epilogue: bias + ReLU (+ 2x2 max-pool over the 4 registers reg&3 of a lane), fp32 math, bf16/f32 store
@@ -632,6 +715,7 @@ __global__ void k_validate_batch(const float* __restrict__ logits, const long lo
 struct ConvLayer {
     int cin, cin_pad, cout, hw;  // hw = input height = width
     bool pool;
+    bool xcol;      // bf16 first layer: x taps folded into the channels (3 K steps)
     float* wp;      // f32 [Cout][9*cin_pad]  (VA_DTYPE_F32)
     __bf16* wp_bf;  // bf16 [Cout][9*cin_pad] (VA_DTYPE_BF16)
     float* bias;
@@ -652,9 +736,18 @@ struct va_vgg16 {
     float* in_mean;  // device [c_in] or NULL
     float* in_std;
     __bf16* zeros;   // 256 zero bytes (VA_DTYPE_BF16: source of the out-of-image taps)
+    int bf16_variant;  // testing: 0 = automatic tile/staging choice, 1 = 64-channel tiles + single buffer, 2 = DMA ring everywhere
 };
 
 namespace {
+
+constexpr long VA_WIDE_MIN = 512;  // workgroups
+#ifndef VA_RING
+#define VA_RING 3
+#endif
+#ifndef VA_RING_MAXGRID
+#define VA_RING_MAXGRID 1024
+#endif
 
 void pick_brick(int W, int H, int B, int& lgTW, int& lgTH, int& TB)
 {
@@ -692,7 +785,9 @@ int launch_conv(const ConvLayer& L, const float* in, float* out, int B, hipStrea
     const int tiles_b = va_cdiv(B, a.TB);
     // BK = 32 (whole 128-byte lines per pixel, half the barriers) was measured 5 % SLOWER than BK = 16:
     // its 72 KB of LDS per workgroup drops the occupancy from 3 to 2 workgroups per CU.
-    if (L.cout % 128 == 0) {
+    // 128-channel tiles only where they still give every CU two workgroups (not the 14x14 layers at B = 32)
+    const bool wide = L.cout % 128 == 0 && (long)(L.cout / 128) * a.tiles_x * a.tiles_y * tiles_b >= VA_WIDE_MIN;
+    if (wide) {
         a.tiles_n = L.cout / 128;
         const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
         if (L.pool) k_conv3x3_mfma<2, 2, 2, 2, true, 16><<<grid, 256, 0, st>>>(a);
@@ -707,11 +802,12 @@ int launch_conv(const ConvLayer& L, const float* in, float* out, int B, hipStrea
     return VA_OK;
 }
 
-int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, const __bf16* in, void* out, bool out_f32, int B, hipStream_t st)
+int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const __bf16* in, void* out, bool out_f32, int B, hipStream_t st)
 {
     ConvArgsBf a{};
     a.in = in;
     a.zeros = zeros;
+    a.taps_x = L.xcol ? 1 : 3;
     a.wp = L.wp_bf;
     a.bias = L.bias;
     a.out = out;
@@ -723,22 +819,26 @@ int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, const __bf16* in, 
     a.tiles_x = va_cdiv(L.hw, 1 << a.lgTW);
     a.tiles_y = va_cdiv(L.hw, 1 << a.lgTH);
     const int tiles_b = va_cdiv(B, a.TB);
-    if (L.cout % 128 == 0) {
-        a.tiles_n = L.cout / 128;
-        const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
-        if (out_f32) {  // only the last layer (pooled)
-            k_conv3x3_mfma_bf16<2, true, true><<<grid, 256, 0, st>>>(a);
-        } else if (L.pool) {
-            k_conv3x3_mfma_bf16<2, true, false><<<grid, 256, 0, st>>>(a);
-        } else {
-            k_conv3x3_mfma_bf16<2, false, false><<<grid, 256, 0, st>>>(a);
-        }
-    } else {
-        a.tiles_n = L.cout / 64;
-        const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
-        if (L.pool) k_conv3x3_mfma_bf16<1, true, false><<<grid, 256, 0, st>>>(a);
-        else k_conv3x3_mfma_bf16<1, false, false><<<grid, 256, 0, st>>>(a);
+    // Tile width and staging scheme by the number of 128-pixel x 64-channel workgroups the layer has:
+    //  - few (14x14 and, with VA_RING_MAXGRID, 28x28 layers): 64-channel tiles and the 3-deep DMA ring at
+    //    two workgroups per CU (all workgroups resident at once);
+    //  - many: 128-channel tiles, single buffer, four workgroups per CU.
+    const long grid64 = (long)(L.cout / 64) * a.tiles_x * a.tiles_y * tiles_b;
+    const int ksteps = 3 * a.taps_x * (a.Cin / 64);
+    const bool ring = variant == 0 ? (grid64 < VA_RING_MAXGRID && ksteps >= VA_RING) : (variant == 2 && ksteps >= VA_RING);
+    const bool wide = variant == 0 && !ring && L.cout % 128 == 0;
+    a.tiles_n = L.cout / (wide ? 128 : 64);
+    const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
+#define VA_LAUNCH_BF(NT_, NB_)                                                                   \
+    {                                                                                            \
+        if (out_f32) k_conv3x3_mfma_bf16<NT_, true, true, NB_><<<grid, 256, 0, st>>>(a);         \
+        else if (L.pool) k_conv3x3_mfma_bf16<NT_, true, false, NB_><<<grid, 256, 0, st>>>(a);    \
+        else k_conv3x3_mfma_bf16<NT_, false, false, NB_><<<grid, 256, 0, st>>>(a);               \
     }
+    if (ring) VA_LAUNCH_BF(1, VA_RING)
+    else if (wide) VA_LAUNCH_BF(2, 1)
+    else VA_LAUNCH_BF(1, 1)
+#undef VA_LAUNCH_BF
     VA_LAUNCH_CHECK();
     return VA_OK;
 }
@@ -852,6 +952,7 @@ extern "C" int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_di
     int hw = 224, cin = c_in, cin_pad = m->c_in_pad;
     int rc = VA_OK;
     auto fail = [&](int code) { va_vgg16_destroy(m); return code; };
+    if (const char* e = getenv("VA_BF16_VARIANT")) m->bf16_variant = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 0;  // tests only
     if (dtype == VA_DTYPE_BF16) {
         if (hipMalloc(&m->zeros, 256) != hipSuccess || hipMemsetAsync(m->zeros, 0, 256, st) != hipSuccess) {
             va_set_error("va_vgg16_create: hipMalloc failed for the zero line");
@@ -872,7 +973,9 @@ extern "C" int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_di
             va_set_error("va_vgg16_create: hipMalloc failed for conv layer %d", i);
             return fail(VA_ERR_HIP);
         }
-        if (bf) k_pack_conv_w_bf16<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>((const float*)conv_w[i], L.wp_bf, L.cout, L.cin, L.cin_pad);
+        L.xcol = bf && i == 0 && 3 * L.cin <= 64 && L.cin <= 21;
+        if (L.xcol) k_pack_conv_w_bf16_xcol<<<va_cdiv(L.cout * 192, 256), 256, 0, st>>>((const float*)conv_w[i], L.wp_bf, L.cout, L.cin);
+        else if (bf) k_pack_conv_w_bf16<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>((const float*)conv_w[i], L.wp_bf, L.cout, L.cin, L.cin_pad);
         else k_pack_conv_w<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>((const float*)conv_w[i], L.wp, L.cout, L.cin, L.cin_pad);
         if (hipMemcpyAsync(L.bias, conv_b[i], L.cout * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = VA_ERR_HIP;
         cin = cin_pad = L.cout;
@@ -957,13 +1060,18 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
     int cur = 1;
     if (m->dtype == VA_DTYPE_BF16) {
         // bf16 activations live in the same two ping-pong buffers (half their size is used)
-        if (x_is_u8)
+        if (m->conv[0].xcol) {
+            if (x_is_u8)
+                k_nchw_to_nhwc_xcol<unsigned char><<<pgrid, 256, 0, st>>>((const unsigned char*)x, (__bf16*)act[1], B, m->c_in, 224, HW0, m->in_mean, m->in_std);
+            else
+                k_nchw_to_nhwc_xcol<float><<<pgrid, 256, 0, st>>>((const float*)x, (__bf16*)act[1], B, m->c_in, 224, HW0, nullptr, nullptr);
+        } else if (x_is_u8)
             k_nchw_to_nhwc_pad<unsigned char, __bf16><<<pgrid, 256, 0, st>>>((const unsigned char*)x, (__bf16*)act[1], B, m->c_in, HW0, m->c_in_pad, m->in_mean, m->in_std);
         else
             k_nchw_to_nhwc_pad<float, __bf16><<<pgrid, 256, 0, st>>>((const float*)x, (__bf16*)act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
         VA_LAUNCH_CHECK();
         for (int i = 0; i < 13; ++i) {
-            if (int rc = launch_conv_bf16(m->conv[i], m->zeros, (const __bf16*)act[cur], act[cur ^ 1], i == 12, B, st)) return rc;
+            if (int rc = launch_conv_bf16(m->conv[i], m->zeros, m->bf16_variant, (const __bf16*)act[cur], act[cur ^ 1], i == 12, B, st)) return rc;
             cur ^= 1;
         }
     } else {
