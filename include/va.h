@@ -24,6 +24,8 @@
  *                     Sheet03/utils.py:154-171, Sheet03/spatialModel.py:223-228.
  *   va_linear_svm_predict   LinearSVC.predict on the joined descriptors:
  *                     Sheet03/combinedModel.py:38.
+ *   va_vgg16_train_*  the batch-loop body of train(): Sheet03/spatialModel.py:165-182;
+ *   va_vgg16_export/import_state   checkpoint contents: Sheet03/spatialModel.py:234-260.
  *
  * Conventions
  *   - return 0 (VA_OK) or an error code; va_last_error() returns a thread-local message.
@@ -206,6 +208,39 @@ int va_meter_average(va_ctx* ctx, const void* sums, const void* counts, int n_sl
 int va_linear_svm_predict(va_ctx* ctx, const void* x, int n, int dim, const void* coef,
                           const void* intercept, int n_class_rows, void* scores, void* pred,
                           void* stream);
+
+/* ------------------------------------------------------------------ training step --- */
+
+/*
+ * The body of the batch loop of SpatialNetwork.train() / TemporalNetwork.train()
+ * (Sheet03/spatialModel.py:165-182, Sheet03/temporalModel.py:194-211), fp32 models only:
+ * forward in train mode (Dropout(p=0.5) after the three hidden classifier ReLUs; element i of dropout
+ * layer d is kept and doubled iff video_analytics_amd.synth.hash_uniform(dropout_seed, 100 + d)[i] >= 0.5),
+ * mean cross-entropy (nn.CrossEntropyLoss, Sheet03/spatialModel.py:114), backward through the whole network
+ * (max-pool gradient to the first maximum of each window, like torch), then torch.optim.SGD's update of every
+ * parameter (Sheet03/spatialModel.py:116: buf = momentum*buf + grad; p -= lr*buf; no weight decay).
+ *   va_vgg16_train_init   allocates and zeroes the momentum buffers (the only allocation of the training path)
+ *   x, labels (i64 [batch]): device; batch <= 64
+ *   desc: device f32 [batch][desc_dim] or NULL: the train-mode descriptor tap (after the third Dropout:
+ *         Sheet03/spatialModel.py:171-173, quirk 7 of SURVEY.md)
+ *   loss_out: device f32[2] = { mean cross-entropy, number of arg-max hits }, both of the forward pass
+ *             that preceded the update
+ */
+int va_vgg16_train_init(va_vgg16* model, void* stream);
+size_t va_vgg16_train_workspace_bytes(const va_vgg16* model, int batch);
+int va_vgg16_train_step(va_vgg16* model, const void* x, int x_is_u8, const void* labels, int batch,
+                        float lr, float momentum, unsigned long long dropout_seed, void* desc,
+                        void* loss_out, void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * Checkpoints (Sheet03/spatialModel.py:234-260, Sheet03/utils.py:29-35): copy the parameters (which = 0) or the
+ * momentum buffers (which = 1) out to / in from device tensors in the reference's layouts -- conv OIHW
+ * [cout][cin][3][3], fc [out][in] (FC1's input CHW-major), biases [out] -- i.e. what model.state_dict() and
+ * optimizer.state_dict()['state'][..]['momentum_buffer'] hold.
+ */
+int va_vgg16_export_state(va_vgg16* model, int which, void* const* conv_w, void* const* conv_b,
+                          void* const* fc_w, void* const* fc_b, void* stream);
+int va_vgg16_import_state(va_vgg16* model, int which, const void* const* conv_w, const void* const* conv_b,
+                          const void* const* fc_w, const void* const* fc_b, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,8 @@ EXPORTS = [
     "va_tvl1_default_params", "va_tvl1_pyramid_sizes", "va_tvl1_workspace_bytes", "va_tvl1_flow",
     "va_flow_to_stack", "va_selftest_exact_math", "va_tvl1_profile_enable", "va_tvl1_profile_read",
     "va_meter_update", "va_meter_average", "va_linear_svm_predict",
+    "va_vgg16_train_init", "va_vgg16_train_workspace_bytes", "va_vgg16_train_step",
+    "va_vgg16_export_state", "va_vgg16_import_state",
 ]
 
 
@@ -105,6 +107,16 @@ def lib():
     L.va_meter_average.restype = ci
     L.va_linear_svm_predict.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp, vp, vp]
     L.va_linear_svm_predict.restype = ci
+    L.va_vgg16_train_init.argtypes = [vp, vp]
+    L.va_vgg16_train_init.restype = ci
+    L.va_vgg16_train_workspace_bytes.argtypes = [vp, ci]
+    L.va_vgg16_train_workspace_bytes.restype = sz
+    L.va_vgg16_train_step.argtypes = [vp, vp, ci, vp, ci, cf, cf, ctypes.c_ulonglong, vp, vp, vp, sz, vp]
+    L.va_vgg16_train_step.restype = ci
+    L.va_vgg16_export_state.argtypes = [vp, ci, pp, pp, pp, pp, vp]
+    L.va_vgg16_export_state.restype = ci
+    L.va_vgg16_import_state.argtypes = [vp, ci, pp, pp, pp, pp, vp]
+    L.va_vgg16_import_state.restype = ci
     _lib = L
     return L
 

@@ -21,7 +21,7 @@
 //     partial slabs reduced by a second kernel that fuses bias+ReLU (deterministic, no atomics).
 //     FC1's weight is repacked so that the NHWC feature map can be used without a transpose while
 //     keeping the reference's CHW-major flatten order c*49+h*7+w (Sheet03/spatialModel.py:213).
-#include "va_internal.h"
+#include "vgg_internal.h"
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -188,6 +188,8 @@ struct ConvArgs {
     int lgTW, lgTH;     // log2 of the brick's width/height (>= 1)
     int TB;
     int tiles_x, tiles_y, tiles_n;
+    const float* mask;  // training (dgrad): zero the output where mask[same index] <= 0 (NULL: no mask; not with POOL)
+    int linear;         // 1: no ReLU (training: dgrad)
 };
 
 __device__ __forceinline__ void brick_coords(int m, int lgTW, int lgTH, int& xl, int& yl, int& bl)
@@ -338,7 +340,10 @@ __global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
                 if (b >= a.B) continue;
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[mt][nt][4 * g4 + j] + bias, 0.0f);
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = acc[mt][nt][4 * g4 + j] + bias;
+                    if (!a.linear) v[j] = fmaxf(v[j], 0.0f);
+                }
                 if constexpr (POOL) {
                     if (x < W && y < H) {
                         const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
@@ -348,7 +353,10 @@ __global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int xx = x + (j & 1), yy = y + (j >> 1);
-                        if (xx < W && yy < H) a.out[(((size_t)b * H + yy) * W + xx) * a.Cout + n] = v[j];
+                        if (xx < W && yy < H) {
+                            const size_t o = (((size_t)b * H + yy) * W + xx) * a.Cout + n;
+                            a.out[o] = (a.mask && !(a.mask[o] > 0.0f)) ? 0.0f : v[j];
+                        }
                     }
                 }
             }
@@ -712,32 +720,10 @@ __global__ void k_validate_batch(const float* __restrict__ logits, const long lo
 
 // ---------------------------------------------------------------- host side --------------------
 
-struct ConvLayer {
-    int cin, cin_pad, cout, hw;  // hw = input height = width
-    bool pool;
-    bool xcol;      // bf16 first layer: x taps folded into the channels (3 K steps)
-    float* wp;      // f32 [Cout][9*cin_pad]  (VA_DTYPE_F32)
-    __bf16* wp_bf;  // bf16 [Cout][9*cin_pad] (VA_DTYPE_BF16)
-    float* bias;
-};
-
 constexpr int kConvCout[13] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
 constexpr bool kConvPool[13] = {false, true, false, true, false, false, true, false, false, true, false, false, true};
 
 }  // namespace
-
-struct va_vgg16 {
-    va_ctx* ctx;
-    int c_in, c_in_pad, n_classes, desc_dim, dtype;
-    ConvLayer conv[13];
-    float* fcw[4];
-    float* fcb[4];
-    int fc_in[4], fc_out[4];
-    float* in_mean;  // device [c_in] or NULL
-    float* in_std;
-    __bf16* zeros;   // 256 zero bytes (VA_DTYPE_BF16: source of the out-of-image taps)
-    int bf16_variant;  // testing: 0 = automatic tile/staging choice, 1 = 64-channel tiles + single buffer, 2 = DMA ring everywhere
-};
 
 namespace {
 
@@ -768,38 +754,46 @@ void pick_brick(int W, int H, int B, int& lgTW, int& lgTH, int& TB)
         }
 }
 
-int launch_conv(const ConvLayer& L, const float* in, float* out, int B, hipStream_t st)
+int launch_conv_ex(int hw, int cin_pad, int cout, const float* wp, const float* bias, const float* in, float* out,
+                   const float* mask, int linear, bool pool, int B, hipStream_t st)
 {
     ConvArgs a{};
     a.in = in;
-    a.wp = L.wp;
-    a.bias = L.bias;
+    a.wp = wp;
+    a.bias = bias;
     a.out = out;
+    a.mask = mask;
+    a.linear = linear;
     a.B = B;
-    a.H = a.W = L.hw;
-    a.Cin = L.cin_pad;
-    a.Cout = L.cout;
-    pick_brick(L.hw, L.hw, B, a.lgTW, a.lgTH, a.TB);
-    a.tiles_x = va_cdiv(L.hw, 1 << a.lgTW);
-    a.tiles_y = va_cdiv(L.hw, 1 << a.lgTH);
+    a.H = a.W = hw;
+    a.Cin = cin_pad;
+    a.Cout = cout;
+    pick_brick(hw, hw, B, a.lgTW, a.lgTH, a.TB);
+    a.tiles_x = va_cdiv(hw, 1 << a.lgTW);
+    a.tiles_y = va_cdiv(hw, 1 << a.lgTH);
     const int tiles_b = va_cdiv(B, a.TB);
     // BK = 32 (whole 128-byte lines per pixel, half the barriers) was measured 5 % SLOWER than BK = 16:
     // its 72 KB of LDS per workgroup drops the occupancy from 3 to 2 workgroups per CU.
     // 128-channel tiles only where they still give every CU two workgroups (not the 14x14 layers at B = 32)
-    const bool wide = L.cout % 128 == 0 && (long)(L.cout / 128) * a.tiles_x * a.tiles_y * tiles_b >= VA_WIDE_MIN;
+    const bool wide = cout % 128 == 0 && (long)(cout / 128) * a.tiles_x * a.tiles_y * tiles_b >= VA_WIDE_MIN;
     if (wide) {
-        a.tiles_n = L.cout / 128;
+        a.tiles_n = cout / 128;
         const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
-        if (L.pool) k_conv3x3_mfma<2, 2, 2, 2, true, 16><<<grid, 256, 0, st>>>(a);
+        if (pool) k_conv3x3_mfma<2, 2, 2, 2, true, 16><<<grid, 256, 0, st>>>(a);
         else k_conv3x3_mfma<2, 2, 2, 2, false, 16><<<grid, 256, 0, st>>>(a);
     } else {
-        a.tiles_n = L.cout / 64;
+        a.tiles_n = cout / 64;
         const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
-        if (L.pool) k_conv3x3_mfma<2, 2, 2, 1, true, 16><<<grid, 256, 0, st>>>(a);
+        if (pool) k_conv3x3_mfma<2, 2, 2, 1, true, 16><<<grid, 256, 0, st>>>(a);
         else k_conv3x3_mfma<2, 2, 2, 1, false, 16><<<grid, 256, 0, st>>>(a);
     }
     VA_LAUNCH_CHECK();
     return VA_OK;
+}
+
+int launch_conv(const ConvLayer& L, const float* in, float* out, int B, hipStream_t st)
+{
+    return launch_conv_ex(L.hw, L.cin_pad, L.cout, L.wp, L.bias, in, out, nullptr, 0, L.pool, B, st);
 }
 
 int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const __bf16* in, void* out, bool out_f32, int B, hipStream_t st)
@@ -913,6 +907,31 @@ WsPlan plan_ws(const va_vgg16* m, int B)
 
 }  // namespace
 
+int va_conv3x3_f32(int hw, int cin_pad, int cout, const float* wp, const float* bias, const float* in, float* out,
+                   const float* mask, int linear, int pool, int B, hipStream_t st)
+{
+    return launch_conv_ex(hw, cin_pad, cout, wp, bias, in, out, mask, linear, pool != 0, B, st);
+}
+
+int va_fc_f32(const float* A, const float* Wt, const float* bias, float* out, float* slab, int M, int N, int K, int relu, hipStream_t st)
+{
+    return launch_fc(A, Wt, bias, out, slab, M, N, K, relu != 0, st);
+}
+
+size_t va_fc_slab_floats(int M, int N, int K) { return plan_fc(M, N, K).slab_floats; }
+
+int va_input_to_nhwc_f32(const va_vgg16* m, const void* x, int x_is_u8, int B, float* out, hipStream_t st)
+{
+    const int HW0 = 224 * 224;
+    const unsigned pgrid = (unsigned)(B * ((HW0 + 63) / 64));
+    if (x_is_u8)
+        k_nchw_to_nhwc_pad<unsigned char, float><<<pgrid, 256, 0, st>>>((const unsigned char*)x, out, B, m->c_in, HW0, m->c_in_pad, m->in_mean, m->in_std);
+    else
+        k_nchw_to_nhwc_pad<float, float><<<pgrid, 256, 0, st>>>((const float*)x, out, B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
+    VA_LAUNCH_CHECK();
+    return VA_OK;
+}
+
 // FC1..FC4 on an NHWC feature map f [B][7][7][512] (Sheet03/spatialModel.py:213-218).
 static int run_classifier(va_vgg16* m, const float* f, int B, void* desc, void* logits, float* slab, float* const* fcbuf,
                           hipStream_t st)
@@ -1020,11 +1039,16 @@ extern "C" void va_vgg16_destroy(va_vgg16* m)
         if (m->conv[i].wp) (void)hipFree(m->conv[i].wp);
         if (m->conv[i].wp_bf) (void)hipFree(m->conv[i].wp_bf);
         if (m->conv[i].bias) (void)hipFree(m->conv[i].bias);
+        if (m->conv[i].mom_w) (void)hipFree(m->conv[i].mom_w);
+        if (m->conv[i].mom_b) (void)hipFree(m->conv[i].mom_b);
     }
     for (int i = 0; i < 4; ++i) {
         if (m->fcw[i]) (void)hipFree(m->fcw[i]);
         if (m->fcb[i]) (void)hipFree(m->fcb[i]);
+        if (m->fc_mom_w[i]) (void)hipFree(m->fc_mom_w[i]);
+        if (m->fc_mom_b[i]) (void)hipFree(m->fc_mom_b[i]);
     }
+    if (m->zeros_f32) (void)hipFree(m->zeros_f32);
     if (m->zeros) (void)hipFree(m->zeros);
     if (m->in_mean) (void)hipFree(m->in_mean);
     if (m->in_std) (void)hipFree(m->in_std);

@@ -161,6 +161,90 @@ class Vgg16Stream(object):
         return desc, logits
 
 
+    # ---- training (fp32 models only) ----
+
+    def train_init(self):
+        """Allocate and zero the momentum buffers (``tch.optim.SGD(..., momentum=...)``, Sheet03/spatialModel.py:116)."""
+        _ffi.check(_ffi.lib().va_vgg16_train_init(self._h, _ffi.stream_ptr()))
+        self._train_ready = True
+
+    def train_step(self, x, labels, lr, momentum, dropout_seed):
+        """One iteration of the batch loop of ``train()`` (Sheet03/spatialModel.py:165-182): forward in train
+        mode, mean cross-entropy, backward, SGD update.  Returns (stats, descriptors): ``stats`` is a CUDA
+        float32 ``[2]`` = (loss, number of arg-max hits) of the forward pass, ``descriptors`` ``[B,D]`` the
+        train-mode feature tap; nothing synchronises the host."""
+        if not getattr(self, "_train_ready", False):
+            self.train_init()
+        if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype not in (torch.float32, torch.uint8):
+            raise ValueError("Vgg16Stream.train_step: x must be a CUDA float32/uint8 tensor")
+        if x.dim() != 4 or tuple(x.shape[1:]) != (self.c_in, 224, 224):
+            raise ValueError("Vgg16Stream.train_step: x must be [B,%d,224,224], got %s" % (self.c_in, tuple(x.shape)))
+        B = x.shape[0]
+        labels = labels.to(device=x.device, dtype=torch.int64).contiguous()
+        if labels.dim() != 1 or labels.shape[0] != B:
+            raise ValueError("Vgg16Stream.train_step: labels must be [B]")
+        x = x.contiguous()
+        L = _ffi.lib()
+        nbytes = L.va_vgg16_train_workspace_bytes(self._h, B)
+        if nbytes == 0:
+            raise ValueError("Vgg16Stream.train_step: batch %d unsupported (1..64, fp32 model)" % B)
+        ws = _workspace(nbytes, x.device, ("train", self.ws_slot))
+        stats = torch.empty(2, dtype=torch.float32, device=x.device)
+        desc = torch.empty((B, self.desc_dim), dtype=torch.float32, device=x.device)
+        _ffi.check(L.va_vgg16_train_step(self._h, _ffi.ptr(x), int(x.dtype == torch.uint8), _ffi.ptr(labels), B, float(lr),
+                                         float(momentum), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, _ffi.ptr(desc), _ffi.ptr(stats),
+                                         _ffi.ptr(ws), ws.numel(), _ffi.stream_ptr()))
+        return stats, desc
+
+    def _state_tensors(self, device):
+        cin = self.c_in
+        cw, cb = [], []
+        for i in range(13):
+            co = _ffi_conv_cout(i)
+            cw.append(torch.empty((co, cin, 3, 3), dtype=torch.float32, device=device))
+            cb.append(torch.empty((co,), dtype=torch.float32, device=device))
+            cin = co
+        fshapes = [(4096, 512 * 7 * 7), (4096, 4096), (self.desc_dim, 4096), (self.n_classes, self.desc_dim)]
+        fw = [torch.empty(sh, dtype=torch.float32, device=device) for sh in fshapes]
+        fb = [torch.empty((sh[0],), dtype=torch.float32, device=device) for sh in fshapes]
+        return cw, cb, fw, fb
+
+    def export_state(self, momentum=False):
+        """-> dict(conv_w, conv_b, fc_w, fc_b) of CUDA tensors in the reference's layouts: the parameters
+        (``model.state_dict()``) or, with ``momentum=True``, SGD's momentum buffers."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        cw, cb, fw, fb = self._state_tensors(dev)
+        arr, arr4 = ctypes.c_void_p * 13, ctypes.c_void_p * 4
+        _ffi.check(_ffi.lib().va_vgg16_export_state(self._h, int(bool(momentum)), arr(*[t.data_ptr() for t in cw]),
+                                                    arr(*[t.data_ptr() for t in cb]), arr4(*[t.data_ptr() for t in fw]),
+                                                    arr4(*[t.data_ptr() for t in fb]), _ffi.stream_ptr()))
+        return dict(conv_w=cw, conv_b=cb, fc_w=fw, fc_b=fb)
+
+    def import_state(self, state, momentum=False):
+        """Load parameters (or momentum buffers) from dict(conv_w, conv_b, fc_w, fc_b) in the reference's layouts."""
+        if momentum and not getattr(self, "_train_ready", False):
+            self.train_init()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        keep = []
+
+        def p(t):
+            t = t.to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        ref = self._state_tensors("meta")
+        for name, want in zip(("conv_w", "conv_b", "fc_w", "fc_b"), ref):
+            got = state[name]
+            if len(got) != len(want) or any(tuple(g.shape) != tuple(w.shape) for g, w in zip(got, want)):
+                raise ValueError("Vgg16Stream.import_state: %s does not match the model's shapes" % name)
+        arr, arr4 = ctypes.c_void_p * 13, ctypes.c_void_p * 4
+        _ffi.check(_ffi.lib().va_vgg16_import_state(self._h, int(bool(momentum)), arr(*[p(t) for t in state["conv_w"]]),
+                                                    arr(*[p(t) for t in state["conv_b"]]), arr4(*[p(t) for t in state["fc_w"]]),
+                                                    arr4(*[p(t) for t in state["fc_b"]]), _ffi.stream_ptr()))
+        torch.cuda.current_stream().synchronize()  # `keep` must outlive the copies
+        del keep
+
+
 def weights_from_state_dict(state_dict):
     """Weights of a torchvision-style VGG-16 state dict as saved by the reference
     (``checkpoint["model"]``, Sheet03/spatialModel.py:256-261; keys carry the ``module.`` prefix of the
