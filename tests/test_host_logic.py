@@ -227,3 +227,35 @@ def test_weights_from_reference_style_state_dict():
     assert tuple(w["fc_w"][2].shape) == (256, 4096) and len(w["fc_b"]) == 4
     with pytest.raises(ValueError):
         vgg.weights_from_state_dict({"features.0.weight": torch.zeros(1)})
+
+
+def test_multistep_lr_and_the_scheduler_step_loss_quirk():
+    # MultiStepLR([10, 20], gamma 0.1) as torch 0.4 computes it from whatever step() received
+    assert U.multiStepLr(0.1, [10, 20], 0) == 0.1 and U.multiStepLr(0.1, [10, 20], 9) == 0.1
+    assert abs(U.multiStepLr(0.1, [10, 20], 10) - 0.01) < 1e-12 and abs(U.multiStepLr(0.1, [10, 20], 20) - 0.001) < 1e-12
+    # the reference passes the validation loss (Sheet03/spatialModel.py:278): a loss of 4.7 keeps lr, 25.3 cuts it twice
+    assert U.multiStepLr(0.1, [10, 20], 4.7) == 0.1 and abs(U.multiStepLr(0.1, [10, 20], 25.3) - 0.001) < 1e-12
+
+
+def test_state_dict_layout_round_trip():
+    from video_analytics_amd import vgg
+    w = dict(conv_w=[torch.full((1,), float(i)) for i in range(13)], conv_b=[torch.full((1,), 100.0 + i) for i in range(13)],
+             fc_w=[torch.full((1,), 200.0 + i) for i in range(4)], fc_b=[torch.full((1,), 300.0 + i) for i in range(4)])
+    sd = vgg.state_dict_from_weights(w)
+    keys = list(sd.keys())
+    assert keys[0] == "module.features.0.weight" and keys[1] == "module.features.0.bias" and keys[2] == "module.features.2.weight"
+    assert keys[26] == "module.classifier.0.weight" and keys[-1] == "module.classifier.9.bias" and len(keys) == 34
+    back = vgg.weights_from_state_dict(sd)
+    for k in w:
+        assert all(torch.equal(a, b) for a, b in zip(w[k], back[k]))
+
+
+def test_checkpoint_and_performance_files(tmp_path):
+    ck, best = str(tmp_path / "c.pth.tar"), str(tmp_path / "b.pth.tar")
+    U.makeCheckpoint({"epoch": 3, "t": torch.arange(3)}, False, ck, best)
+    assert os.path.isfile(ck) and not os.path.isfile(best)
+    U.makeCheckpoint({"epoch": 4, "t": torch.arange(3)}, True, ck, best)
+    assert torch.load(best, weights_only=True)["epoch"] == 4
+    perf = str(tmp_path / "perf.csv")
+    U.savePerformance(0.25, 3.5, perf); U.savePerformance(0.5, 2.5, perf)
+    assert open(perf).read() == "0.25,3.5\n0.5,2.5\n"

@@ -92,3 +92,71 @@ def test_export_import_round_trip():
     with pytest.raises(ValueError):
         m.import_state(dict(w, conv_w=w["conv_w"][:12]))
     m.close()
+
+
+class _MemDataset(torch.utils.data.Dataset):
+    def __init__(self, x, labels, prefix):
+        self.x, self.labels, self.prefix = x, labels, prefix
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def __getitem__(self, i):
+        return self.x[i], int(self.labels[i]), "v_%s_g01_c%02d" % (self.prefix, i + 1)
+
+
+def test_execute_trains_validates_checkpoints_and_resumes(tmp_path, monkeypatch):
+    """SpatialNetwork.execute() with a train loader (Sheet03/spatialModel.py:265-283): per epoch train + validate,
+    checkpoint with the reference's keys, performance CSV, descriptor CSVs, best-model copy, the
+    scheduler.step(loss) quirk, and resume() from the checkpoint into a fresh object."""
+    import csv
+    import os
+    from torch.utils.data import DataLoader
+    from video_analytics_amd import synth, spatialModel
+    from video_analytics_amd.spatialModel import SpatialNetwork
+    monkeypatch.chdir(tmp_path)
+    for name in ("TRAIN_CSV", "TEST_CSV", "PERFORMANCE_CSV"):
+        monkeypatch.setattr(SpatialNetwork, name, str(tmp_path / (name.lower() + ".csv")))
+    w = synth.synth_vgg16_weights(c_in=3, seed=9)
+    xs = torch.from_numpy(synth.hash_uniform(90, 1, 5 * 3 * 224 * 224).reshape(5, 3, 224, 224) * 4.0 - 2.0)
+    train = DataLoader(_MemDataset(xs[:4], [1, 2, 3, 4], "Train"), batch_size=2, shuffle=False, num_workers=0)
+    test = DataLoader(_MemDataset(xs[2:], [3, 4, 5], "Test"), batch_size=2, shuffle=False, num_workers=0)
+    ckp = str(tmp_path / "ckp")
+    net = SpatialNetwork(101, 2, 1e-4, 0.9, 256, train, test, [10, 20], ckp, gpu=True,
+                         weights={k: [t.clone() for t in v] for k, v in w.items()})
+    precision, loss = net.execute()
+    assert net.epoch == 1 and 0.0 <= precision <= 1.0 and float(loss) > 0
+    assert len(net.lastTrainStats) == 2 and all(float(t[0]) > 0 for t in net.lastTrainStats)
+    rows = list(csv.reader(open(SpatialNetwork.PERFORMANCE_CSV)))
+    assert len(rows) == 2 and float(rows[1][0]) == precision
+    assert len(list(csv.reader(open(SpatialNetwork.TRAIN_CSV)))) == 4 and len(list(csv.reader(open(SpatialNetwork.TEST_CSV)))) == 3
+    # scheduler.step(loss): the loss value is what MultiStepLR sees as the epoch
+    assert net.schedulerLastEpoch == float(loss)
+    assert abs(net.currentLr() - 1e-4 * 0.1 ** sum(float(loss) >= ms for ms in (10, 20))) < 1e-12
+    ck = torch.load(os.path.join(ckp, "spatial_ckp.pth.tar"), weights_only=True)
+    assert set(ck.keys()) >= {"epoch", "model", "highestPrecision", "optimizer"} and ck["epoch"] == 1
+    assert list(ck["model"].keys())[:2] == ["module.features.0.weight", "module.features.0.bias"]
+    assert len(ck["model"]) == 34 and len(ck["optimizer"]["state"]) == 34
+    assert ck["optimizer"]["param_groups"][0]["momentum"] == 0.9
+    moved = float((ck["model"]["module.classifier.9.weight"] - w["fc_w"][3]).abs().max())
+    assert moved > 0  # the parameters were really updated
+    if net.isBest:
+        assert os.path.isfile(os.path.join(ckp, "spatial_best.pth.tar"))
+    trained = net.model.export_state()
+    net.model.close()
+    # a fresh object resumes: epoch counter, parameters and momentum come from the checkpoint
+    net2 = SpatialNetwork(101, 3, 1e-4, 0.9, 256, train, test, [10, 20], ckp, gpu=True,
+                          weights={k: [t.clone() for t in v] for k, v in w.items()})
+    assert net2.resume() and net2.startEpoch == 2 and net2.schedulerLastEpoch == 2
+    got = net2.model.export_state()
+    for k in got:
+        for a, b in zip(got[k], trained[k]):
+            assert torch.equal(a, b)
+    gotm = net2.model.export_state(momentum=True)
+    assert torch.equal(gotm["fc_w"][3].cpu(), ck["optimizer"]["state"][32]["momentum_buffer"])
+    net2.model.close()
+    # no checkpoint directory: resume() reports False
+    net3 = SpatialNetwork(101, 1, 1e-4, 0.9, 256, None, test, [10, 20], str(tmp_path / "none"), gpu=True,
+                          weights={k: [t.clone() for t in v] for k, v in w.items()})
+    assert net3.resume() is False
+    net3.model.close()

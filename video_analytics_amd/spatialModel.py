@@ -9,6 +9,7 @@ this inference path and raise NotImplementedError.
 from __future__ import division
 
 import os
+import time
 import random  # noqa: F401  (the dataset draws from the global random state, like the reference)
 
 import torch
@@ -18,7 +19,8 @@ from torch.utils.data import Dataset
 from . import fusion, synth, vgg
 from .parameters import *  # noqa: F401,F403
 from .parameters import (FRAME_EXTN, NORM_MEANS_TF, NORM_STDS_TF, SPATIAL_TEST_CSV_LOC, VIDEO_INPUT_FRAME_COUNT)
-from .utils import AverageMeter, ToTensor, saveVideoDescriptors, spatialFrameIndex, videoInfo
+from .utils import (AverageMeter, ToTensor, checkAndMakeDirectories, makeCheckpoint, multiStepLr, savePerformance,
+                    saveVideoDescriptors, spatialFrameIndex, videoInfo)
 
 
 def _read_label_dict(actionLabelLoc):
@@ -80,6 +82,8 @@ class SpatialNetwork(object):
         self.nActionClasses = nActionClasses
         self.nEpochs = nEpochs
         self.lr = lr
+        self.momentumVal = momentumVal
+        self.schedulerLastEpoch = 0  # MultiStepLR(..., last_epoch=-1) steps once on construction
         self.trainLoader = trainLoader
         self.totalTrain = len(self.trainLoader.dataset) if trainLoader is not None else 0
         self.testLoader = testLoader
@@ -104,6 +108,7 @@ class SpatialNetwork(object):
         self.trainDict = {}
         self.testDict = {}
         self.testMeters = fusion.DescriptorMeters(descriptorDim, self.device)  # persists across epochs (quirk 7)
+        self.trainMeters = fusion.DescriptorMeters(descriptorDim, self.device)
 
     def _build(self, weights):
         return vgg.Vgg16Stream(weights["conv_w"], weights["conv_b"], weights["fc_w"], weights["fc_b"],
@@ -131,18 +136,100 @@ class SpatialNetwork(object):
               % (self.epoch, self.totalTest, correct, float(loss)))
         return (correct / self.totalTest), loss
 
-    def execute(self):
-        """Inference-only ``execute``: one validation pass + the per-video descriptor CSV
-        (Sheet03/spatialModel.py:274,283)."""
-        precision, loss = self.validate()
-        saveVideoDescriptors(self.testDict, SPATIAL_TEST_CSV_LOC, self.gpu)
-        return precision, loss
+    # ---- training: Sheet03/spatialModel.py:157-194, 234-283 ----
+
+    CKP_FILE, BEST_FILE = SPATIAL_CKP_FILE, SPATIAL_BEST_FILE
+    TRAIN_CSV, TEST_CSV, PERFORMANCE_CSV = SPATIAL_TRAIN_CSV_LOC, SPATIAL_TEST_CSV_LOC, SPATIAL_PERFORMANCE_LOC
+
+    def currentLr(self):
+        """The optimiser's learning rate: MultiStepLR over what the reference feeds it (see ``multiStepLr``)."""
+        return multiStepLr(self.lr, self.lrMilestones, self.schedulerLastEpoch)
 
     def train(self):
-        raise NotImplementedError("training is outside the inference hot path (SURVEY.md section 8f)")
+        """Train for an epoch (Sheet03/spatialModel.py:157-194): every batch is one fused forward / backward /
+        SGD step on the GPU (``va_vgg16_train_step``); the train-mode descriptors are collated per video
+        (quirk 7 of SURVEY.md: Dropout is active in them)."""
+        if self.trainLoader is None:
+            raise ValueError("train(): no trainLoader")
+        startTime = time.time()
+        lr = self.currentLr()
+        pending = []
+        for iBatch, (data, labels, videoNames) in enumerate(self.trainLoader):
+            ip = data.to(self.device, non_blocking=True)
+            # Dropout masks: the reference draws them from torch's global generator; here they are a pure function
+            # of (epoch, batch index) so that a run can be reproduced (and checked against the CPU oracle)
+            stats, featureVectors = self.model.train_step(ip, labels, lr, self.momentumVal, self.epoch * 1000003 + iBatch)
+            pending.append(stats)
+            self.trainMeters.update(featureVectors, videoNames, labels)
+        # (Sheet03/spatialModel.py:190 clips the gradient norm AFTER the last optimizer.step() of the epoch: it never
+        # changes an update, so there is nothing to do here.)
+        self.trainDict = self.trainMeters.as_dict()
+        self.lastTrainStats = [t.cpu() for t in pending]
+        print("Epoch %d completed in %f seconds" % (self.epoch, time.time() - startTime))
+        self.save()
 
-    def resume(self):
-        raise NotImplementedError("checkpoint resume is training bookkeeping (SURVEY.md section 8f)")
+    def state(self):
+        """What the reference checkpoints (Sheet03/spatialModel.py:256-261): epoch, model.state_dict() (``module.``
+        keys), highestPrecision, optimizer.state_dict() (momentum buffers in parameter order + the param group)."""
+        params = self.model.export_state()
+        names = list(vgg.state_dict_from_weights(params).keys())
+        opt = {"state": {}, "param_groups": [{"lr": self.currentLr(), "initial_lr": self.lr, "momentum": self.momentumVal,
+                                              "dampening": 0, "weight_decay": 0, "nesterov": False,
+                                              "params": list(range(len(names)))}]}
+        if getattr(self.model, "_train_ready", False):
+            mom = list(vgg.state_dict_from_weights(self.model.export_state(momentum=True)).values())
+            opt["state"] = {i: {"momentum_buffer": t.cpu()} for i, t in enumerate(mom)}
+        return {"epoch": self.epoch,
+                "model": type(vgg.state_dict_from_weights(params))((k, v.cpu()) for k, v in vgg.state_dict_from_weights(params).items()),
+                "highestPrecision": self.highestPrecision, "optimizer": opt,
+                "schedulerLastEpoch": self.schedulerLastEpoch}
 
     def save(self):
-        raise NotImplementedError("checkpoint save is training bookkeeping (SURVEY.md section 8f)")
+        """Sheet03/spatialModel.py:252-262."""
+        if self.ckpLoc is None:
+            return
+        checkAndMakeDirectories(self.ckpLoc)
+        makeCheckpoint(self.state(), self.isBest, self.ckpLoc + self.CKP_FILE, self.ckpLoc + self.BEST_FILE)
+
+    def resume(self):
+        """Sheet03/spatialModel.py:234-250: continue from ``ckpLoc + CKP_FILE`` if it exists."""
+        resumeLoc = None if self.ckpLoc is None else self.ckpLoc + self.CKP_FILE
+        if not (resumeLoc and os.path.isfile(resumeLoc)):
+            print("No checkpoints found; starting from scratch!")
+            return False
+        print("Resuming training from checkpoint file: %s" % resumeLoc)
+        checkpoint = torch.load(resumeLoc, map_location="cpu", weights_only=True)
+        self.startEpoch = checkpoint["epoch"] + 1
+        self.highestPrecision = checkpoint["highestPrecision"]
+        self.model.import_state(vgg.weights_from_state_dict(checkpoint["model"]))
+        st = checkpoint["optimizer"]["state"]
+        if len(st):
+            names = list(checkpoint["model"].keys())
+            self.model.import_state(vgg.weights_from_state_dict({n: st[i]["momentum_buffer"] for i, n in enumerate(names)}),
+                                    momentum=True)
+        # the reference rebuilds MultiStepLR with last_epoch = startEpoch (Sheet03/spatialModel.py:248)
+        self.schedulerLastEpoch = self.startEpoch
+        print("Loaded checkpoint: starting from epoch: %d" % self.startEpoch)
+        return True
+
+    def execute(self):
+        """All epochs, each = train + validate (Sheet03/spatialModel.py:265-283).  Without a trainLoader this is
+        the inference-only pass: one validation + the per-video descriptor CSV."""
+        if self.trainLoader is None:
+            precision, loss = self.validate()
+            saveVideoDescriptors(self.testDict, self.TEST_CSV, self.gpu)
+            return precision, loss
+        self.resume()
+        precision, loss = None, None
+        for self.epoch in range(self.startEpoch, self.nEpochs):
+            self.train()
+            precision, loss = self.validate()
+            if precision > self.highestPrecision:
+                self.highestPrecision = precision
+                self.isBest = True  # (never reset in the reference either: every later save also refreshes the best file)
+            self.schedulerLastEpoch = float(loss)  # scheduler.step(loss): the loss lands where the epoch belongs (quirk)
+            self.save()
+            savePerformance(precision, float(loss), self.PERFORMANCE_CSV)
+            saveVideoDescriptors(self.trainDict, self.TRAIN_CSV, self.gpu)
+            saveVideoDescriptors(self.testDict, self.TEST_CSV, self.gpu)
+        return precision, loss

@@ -95,7 +95,5 @@ class TemporalNetwork(SpatialNetwork):
         return vgg.Vgg16Stream(weights["conv_w"], weights["conv_b"], weights["fc_w"], weights["fc_b"],
                                self.nActionClasses, self.descriptorDim, device=self.device.index)
 
-    def execute(self):
-        precision, loss = self.validate()
-        saveVideoDescriptors(self.testDict, TEMPORAL_TEST_CSV_LOC, self.gpu)
-        return precision, loss
+    CKP_FILE, BEST_FILE = MOTION_CKP_FILE, MOTION_BEST_FILE
+    TRAIN_CSV, TEST_CSV, PERFORMANCE_CSV = TEMPORAL_TRAIN_CSV_LOC, TEMPORAL_TEST_CSV_LOC, TEMPORAL_PERFORMANCE_LOC

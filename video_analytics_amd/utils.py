@@ -12,6 +12,7 @@ from __future__ import division
 
 import csv
 import os
+import shutil
 import random
 
 import numpy as np
@@ -32,6 +33,27 @@ def checkAndMakeDirectories(*args):
             exists[i] = False
             os.makedirs(arg)
     return exists
+
+
+def makeCheckpoint(modelState, isBest, ckpLoc, bestModel):
+    """Save the training state; copy it to ``bestModel`` when ``isBest`` (Sheet03/utils.py:29-35)."""
+    torch.save(modelState, ckpLoc)
+    if isBest:
+        shutil.copyfile(ckpLoc, bestModel)
+
+
+def savePerformance(precision, loss, csvLoc):
+    """Append ``precision,loss`` of one epoch (Sheet03/utils.py:198-205)."""
+    with open(csvLoc, "a") as csvFile:
+        csvFile.write(str(precision) + "," + str(loss) + "\n")
+
+
+def multiStepLr(baseLr, milestones, lastEpoch, gamma=0.1):
+    """``MultiStepLR.get_lr()`` of torch 0.4 (the reference's scheduler, Sheet03/spatialModel.py:119):
+    baseLr * gamma ** bisect_right(milestones, lastEpoch).  ``lastEpoch`` is whatever was passed to
+    ``scheduler.step(...)`` -- the reference passes the validation LOSS (Sheet03/spatialModel.py:278, quirk)."""
+    import bisect
+    return baseLr * gamma ** bisect.bisect_right(sorted(milestones), lastEpoch)
 
 
 def videoInfo(line, mode):

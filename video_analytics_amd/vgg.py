@@ -264,6 +264,25 @@ def weights_from_state_dict(state_dict):
         raise ValueError("weights_from_state_dict: missing key %s (not a VGG-16 'D' + 4-layer classifier state dict)" % e)
 
 
+CONV_IDX = [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]  # Conv2d positions in VGG-16 'D' features
+FC_IDX = [0, 3, 6, 9]                                          # Linear positions in the swapped classifier
+
+
+def state_dict_from_weights(weights, prefix="module."):
+    """dict(conv_w, conv_b, fc_w, fc_b) -> an ordered torchvision-style state dict with the ``module.`` prefix the
+    reference's ``nn.DataParallel`` wrapper gives its keys (Sheet03/spatialModel.py:133,258): the inverse of
+    ``weights_from_state_dict``; also the order of ``model.parameters()`` (weight, bias per layer)."""
+    from collections import OrderedDict
+    sd = OrderedDict()
+    for i, k in enumerate(CONV_IDX):
+        sd["%sfeatures.%d.weight" % (prefix, k)] = weights["conv_w"][i]
+        sd["%sfeatures.%d.bias" % (prefix, k)] = weights["conv_b"][i]
+    for i, k in enumerate(FC_IDX):
+        sd["%sclassifier.%d.weight" % (prefix, k)] = weights["fc_w"][i]
+        sd["%sclassifier.%d.bias" % (prefix, k)] = weights["fc_b"][i]
+    return sd
+
+
 def _ffi_conv_cout(i):
     return (64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512)[i]
 
