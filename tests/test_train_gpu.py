@@ -160,3 +160,24 @@ def test_execute_trains_validates_checkpoints_and_resumes(tmp_path, monkeypatch)
                           weights={k: [t.clone() for t in v] for k, v in w.items()})
     assert net3.resume() is False
     net3.model.close()
+
+
+def test_large_batch_step_is_deterministic():
+    """Batch 40 takes the 64-row instantiations of the classifier kernels and crosses a batch brick of the
+    convolution tiles.  No CPU oracle at this size (minutes on 8 cores): two runs from the same state must give
+    bit-identical statistics, descriptors and parameters (there are no atomics anywhere in the step)."""
+    from video_analytics_amd import synth, vgg
+    w = synth.synth_vgg16_weights(c_in=3, seed=12)
+    x = torch.from_numpy(synth.hash_uniform(91, 2, 40 * 3 * 224 * 224).reshape(40, 3, 224, 224) * 4.0 - 2.0).cuda()
+    y = torch.arange(40, dtype=torch.int64) % 101
+    outs = []
+    for _ in range(2):
+        m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256)
+        stats, desc = m.train_step(x, y, 1e-4, 0.9, 77)
+        st = m.export_state()
+        outs.append((stats.cpu(), desc.cpu(), [t.cpu() for k in ("conv_w", "conv_b", "fc_w", "fc_b") for t in st[k]]))
+        m.close()
+    assert torch.isfinite(outs[0][0]).all() and float(outs[0][0][0]) > 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][2], outs[1][2]))
+    assert any(not torch.equal(a, b) for a, b in zip(outs[0][2][:26:2], w["conv_w"]))  # conv weights moved
