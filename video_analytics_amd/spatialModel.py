@@ -3,8 +3,8 @@
 ``SpatialDataset`` keeps the reference's indexing and file layout bit for bit; ``SpatialNetwork``
 keeps the constructor signature and ``validate()`` (the inference hot loop,
 Sheet03/spatialModel.py:197-231).  The forward pass runs in libva_hip.so (``vgg.Vgg16Stream``).
-``train`` / ``resume`` / ``save`` are the training loop and checkpoint bookkeeping: out of scope of
-this inference path and raise NotImplementedError.
+``train`` / ``resume`` / ``save`` / ``execute`` (Sheet03/spatialModel.py:157-194, 234-283) run the training
+step on the GPU as well (``Vgg16Stream.train_step``: SURVEY.md section 8f rank 4).
 """
 from __future__ import division
 
@@ -69,7 +69,7 @@ class SpatialDataset(Dataset):
 
 
 class SpatialNetwork(object):
-    """Wrapper of the spatial stream (Sheet03/spatialModel.py:85-283), inference part."""
+    """Wrapper of the spatial stream (Sheet03/spatialModel.py:85-283)."""
 
     C_IN = 3
 

@@ -69,7 +69,7 @@ def flowVolumesFromFrames(gray, flowSampleSize=VIDEO_INPUT_FLOW_COUNT, tvl1_para
 
 
 class TemporalNetwork(SpatialNetwork):
-    """Wrapper of the motion stream (Sheet03/temporalModel.py:96-312), inference part."""
+    """Wrapper of the motion stream (Sheet03/temporalModel.py:96-312)."""
 
     def __init__(self, nActionClasses, flowSampleSize, nEpochs, lr, momentumVal, descriptorDim, trainLoader, testLoader,
                  lrMilestones, ckpLoc, gpu=False, weights=None, seed=2):
