@@ -157,7 +157,7 @@ class SpatialNetwork(object):
         for iBatch, (data, labels, videoNames) in enumerate(self.trainLoader):
             ip = data.to(self.device, non_blocking=True)
             # Dropout masks: the reference draws them from torch's global generator; here they are a pure function
-            # of (epoch, batch index) so that a run can be reproduced (and checked against the CPU oracle)
+            # of (epoch, batch index) so that a run can be reproduced (and re-derived on the CPU by the tests)
             stats, featureVectors = self.model.train_step(ip, labels, lr, self.momentumVal, self.epoch * 1000003 + iBatch)
             pending.append(stats)
             self.trainMeters.update(featureVectors, videoNames, labels)
