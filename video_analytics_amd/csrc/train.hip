@@ -580,7 +580,7 @@ extern "C" int va_vgg16_train_step(va_vgg16* m, const void* x, int x_is_u8, cons
     const float* in = F(T.x0);
     for (int i = 0; i < 13; ++i) {
         const ConvLayer& L = m->conv[i];
-        if (int rc = va_conv3x3_f32(L.hw, L.cin_pad, L.cout, L.wp, L.bias, in, F(T.y[i]), nullptr, 0, 0, B, st)) return rc;
+        if (int rc = va_conv3x3_f32(L.hw, L.cin_pad, L.cout, L.wp, L.bias, in, F(T.y[i]), nullptr, 0, 0, B, m->zeros_f32, st)) return rc;
         in = F(T.y[i]);
         if (L.pool) {
             const size_t n = (size_t)B * (L.hw / 2) * (L.hw / 2) * (L.cout / 4);
@@ -647,7 +647,7 @@ extern "C" int va_vgg16_train_step(va_vgg16* m, const void* x, int x_is_u8, cons
             k_pack_dgrad_w<<<(unsigned)((nwt + 255) / 256), 256, 0, st>>>(L.wp, F(T.wt), L.cout, L.cin_pad, cin);
             float* g = F(T.g[1 - cur]);
             const float* mask = m->conv[i - 1].pool ? nullptr : F(T.y[i - 1]);
-            if (int rc = va_conv3x3_f32(L.hw, L.cout, cin, F(T.wt), m->zeros_f32, dyr, g, mask, 1, 0, B, st)) return rc;
+            if (int rc = va_conv3x3_f32(L.hw, L.cout, cin, F(T.wt), m->zeros_f32, dyr, g, mask, 1, 0, B, m->zeros_f32, st)) return rc;
             dout = g;
         }
         // weight and bias gradients + update (dyr stays intact: the data gradient went to the other buffer)

@@ -190,6 +190,7 @@ struct ConvArgs {
     int tiles_x, tiles_y, tiles_n;
     const float* mask;  // training (dgrad): zero the output where mask[same index] <= 0 (NULL: no mask; not with POOL)
     int linear;         // 1: no ReLU (training: dgrad)
+    const float* zeros; // DMA kernel: >= 16 zero bytes, the source of every out-of-image tap
 };
 
 __device__ __forceinline__ void brick_coords(int m, int lgTW, int lgTH, int& xl, int& yl, int& bl)
@@ -593,6 +594,193 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) k_conv3x3_mfma_bf16(Co
     }
 }
 
+// ---------------------------------------------------------------- fp32 conv3x3, LDS-DMA staging ---------
+//
+// The bf16 kernel's structure (LDS-DMA with source-side swizzle, one 32 KB buffer, four workgroups per CU, or
+// the DMA ring for small grids) with fp32 data: K step = 32 channels (a 128-byte line per pixel), 16-byte
+// fragment reads feed four v_mfma_f32_32x32x2_f32 each (lane half hh holds k = 8*ks + 4*hh + j for both
+// operands).  Needs Cin % 32 == 0.
+constexpr int kDmaBK = 32;
+
+template <int NT, bool POOL, int NBUF>
+__global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) k_conv3x3_dma_f32(ConvArgs a)
+{
+    constexpr int BM = 128, BN = NT * 64, MT = 2;
+    constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;  // LDS-DMA instructions per wave and K step (8 rows each)
+    constexpr int TILE = (BM + BN) * kDmaBK;  // bf16 elements of one K step's A and B tiles
+    __shared__ __attribute__((aligned(1024))) float smem[NBUF * TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bid = blockIdx.x;
+    const int n_tile = bid % a.tiles_n;
+    bid /= a.tiles_n;
+    const int tile_x = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int tile_y = bid % a.tiles_y;
+    const int tile_b = bid / a.tiles_y;
+    const int n0 = n_tile * BN;
+    const int H = a.H, W = a.W, Cin = a.Cin;
+    const int X0 = tile_x << a.lgTW, Y0 = tile_y << a.lgTH, B0 = tile_b * a.TB;
+
+    // loader role: row (lane >> 3) of the 8-row group, slot (lane & 7)
+    const int lrow = lane >> 3, lslot = lane & 7;
+    int ax[A_INSTR], ay[A_INSTR];
+    long apix[A_INSTR];
+    bool aok[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int row = (wave * A_INSTR + i) * 8 + lrow;
+        const int c = lslot ^ ((row >> 1) & 7);
+        int xl, yl, bl;
+        brick_coords(row, a.lgTW, a.lgTH, xl, yl, bl);
+        ax[i] = X0 + xl;
+        ay[i] = Y0 + yl;
+        const int b = B0 + bl;
+        aok[i] = b < a.B && ax[i] < W && ay[i] < H;
+        apix[i] = (((long)b * H + ay[i]) * W + ax[i]) * Cin + 4 * c;
+    }
+    const float* wrow[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int row = (wave * B_INSTR + i) * 8 + lrow;
+        wrow[i] = a.wp + (size_t)(n0 + row) * 9 * Cin + 4 * (lslot ^ ((row >> 1) & 7));
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    const int cchunks = Cin / kDmaBK;
+    const int T = 9 * cchunks;
+    const int r31 = lane & 31, hh = lane >> 5;
+    const int fsw = (r31 >> 1) & 7;  // fragment rows are (multiple of 32) + r31
+    int kp = 0, c0 = 0;
+    // LDS-DMA of K step (kp, c0) into ring slot `buf`; advances (kp, c0)
+    auto stage = [&](int buf) {
+        float* const sA = smem + buf * TILE;
+        float* const sB = sA + BM * kDmaBK;
+        const int ky = kp / 3 - 1, kx = kp % 3 - 1;
+        const long tap = ((long)ky * W + kx) * Cin + c0;
+        static_for<A_INSTR>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const int yy = ay[i] + ky, xx = ax[i] + kx;
+            const bool ok = aok[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float* src = ok ? a.in + apix[i] + tap : a.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sA + (wave * A_INSTR + i) * 8 * kDmaBK), 16, 0, 0);
+        });
+        static_for<B_INSTR>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wrow[i] + (size_t)kp * Cin + c0),
+                                             (lds_ptr_t)(sB + (wave * B_INSTR + i) * 8 * kDmaBK), 16, 0, 0);
+        });
+        c0 += kDmaBK;
+        if (c0 == Cin) {
+            c0 = 0;
+            ++kp;
+        }
+    };
+    auto compute = [&](int buf) {
+        const float* const sA = smem + buf * TILE;
+        const float* const sB = sA + BM * kDmaBK;
+#pragma unroll
+        for (int ks = 0; ks < kDmaBK / 8; ++ks) {
+            f32x4 fa[MT], fb[NT];
+            const int slot = ((2 * ks + hh) ^ fsw) * 4;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                fa[mt] = *reinterpret_cast<const f32x4*>(&sA[((wm * MT + mt) * 32 + r31) * kDmaBK + slot]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                fb[nt] = *reinterpret_cast<const f32x4*>(&sB[((wn * NT + nt) * 32 + r31) * kDmaBK + slot]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt][j], fb[nt][j], acc[mt][nt], 0, 0, 0);
+        }
+    };
+    if constexpr (NBUF == 1) {
+        for (int t = 0; t < T; ++t) {
+            stage(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();  // every wave has read the tile before the next DMA overwrites it
+        }
+    } else {
+        constexpr int LOADS = A_INSTR + B_INSTR;  // this wave's DMA instructions per K step
+        // prologue: NBUF-1 steps in flight (T >= 3 >= NBUF-1 is not guaranteed for NBUF > 4: launch only NBUF <= 4)
+        for (int j = 0; j < NBUF - 1 && j < T; ++j) stage(j);
+        int slot = 0;
+        for (int t = 0; t < T; ++t) {
+            // wait until this wave's DMAs of step t have landed: steps t+1 .. t+NBUF-2 may stay in flight
+            if (t + NBUF - 2 < T) {
+                if constexpr ((NBUF - 2) * LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if constexpr ((NBUF - 2) * LOADS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if constexpr ((NBUF - 2) * LOADS == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if constexpr ((NBUF - 2) * LOADS == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // all waves: step t's tile is complete, and step t-1's reads are done, so its slot can be refilled
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + NBUF - 1 < T) stage(slot == 0 ? NBUF - 1 : slot - 1);
+            compute(slot);
+            slot = slot + 1 == NBUF ? 0 : slot + 1;
+        }
+    }
+
+    // epilogue: bias + ReLU (+ 2x2 max-pool over the 4 registers reg&3 of a lane)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + (wn * NT + nt) * 32 + r31;
+        const float bias = a.bias[n];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                // rows m = (wm*MT+mt)*32 + 8*g4 + 4*hh + (0..3)
+                const int mbase = (wm * MT + mt) * 32 + 8 * g4 + 4 * hh;
+                int xl, yl, bl;
+                brick_coords(mbase, a.lgTW, a.lgTH, xl, yl, bl);
+                const int x = X0 + xl, y = Y0 + yl, b = B0 + bl;  // (x,y) even: the 2x2 window's origin
+                if (b >= a.B) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = acc[mt][nt][4 * g4 + j] + bias;
+                    if (!a.linear) v[j] = fmaxf(v[j], 0.0f);
+                }
+                if constexpr (POOL) {
+                    if (x < W && y < H) {
+                        const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        a.out[((((size_t)b * (H >> 1)) + (y >> 1)) * (W >> 1) + (x >> 1)) * a.Cout + n] = mx;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int xx = x + (j & 1), yy = y + (j >> 1);
+                        if (xx < W && yy < H) {
+                            const size_t o = (((size_t)b * H + yy) * W + xx) * a.Cout + n;
+                            a.out[o] = (a.mask && !(a.mask[o] > 0.0f)) ? 0.0f : v[j];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+
 // ---------------------------------------------------------------- FC split-K GEMM --------------
 
 struct FcArgs {
@@ -734,6 +922,15 @@ constexpr long VA_WIDE_MIN = 512;  // workgroups
 #ifndef VA_RING_MAXGRID
 #define VA_RING_MAXGRID 1024
 #endif
+#ifndef VA_F32_CONV_DEFAULT
+#define VA_F32_CONV_DEFAULT 1
+#endif
+#ifndef VA_CIN_ALIGN
+#define VA_CIN_ALIGN 16
+#endif
+#ifndef VA_RING_MAXGRID_F32
+#define VA_RING_MAXGRID_F32 1024
+#endif
 
 void pick_brick(int W, int H, int B, int& lgTW, int& lgTH, int& TB)
 {
@@ -755,7 +952,7 @@ void pick_brick(int W, int H, int B, int& lgTW, int& lgTH, int& TB)
 }
 
 int launch_conv_ex(int hw, int cin_pad, int cout, const float* wp, const float* bias, const float* in, float* out,
-                   const float* mask, int linear, bool pool, int B, hipStream_t st)
+                   const float* mask, int linear, bool pool, int B, const float* zeros, hipStream_t st)
 {
     ConvArgs a{};
     a.in = in;
@@ -764,6 +961,7 @@ int launch_conv_ex(int hw, int cin_pad, int cout, const float* wp, const float* 
     a.out = out;
     a.mask = mask;
     a.linear = linear;
+    a.zeros = zeros;
     a.B = B;
     a.H = a.W = hw;
     a.Cin = cin_pad;
@@ -772,8 +970,31 @@ int launch_conv_ex(int hw, int cin_pad, int cout, const float* wp, const float* 
     a.tiles_x = va_cdiv(hw, 1 << a.lgTW);
     a.tiles_y = va_cdiv(hw, 1 << a.lgTH);
     const int tiles_b = va_cdiv(B, a.TB);
-    // BK = 32 (whole 128-byte lines per pixel, half the barriers) was measured 5 % SLOWER than BK = 16:
-    // its 72 KB of LDS per workgroup drops the occupancy from 3 to 2 workgroups per CU.
+    static const int f32_conv = [] {
+        const char* e = getenv("VA_F32_CONV");  // A/B testing: 0 = register-staged kernel, 1 = LDS-DMA kernel
+        return e ? atoi(e) : VA_F32_CONV_DEFAULT;
+    }();
+    if (f32_conv == 1 && zeros != nullptr && cin_pad % kDmaBK == 0) {
+        const long grid64 = (long)(cout / 64) * a.tiles_x * a.tiles_y * tiles_b;
+        const int ksteps = 9 * (cin_pad / kDmaBK);
+        const bool ring = grid64 < VA_RING_MAXGRID_F32 && ksteps >= VA_RING;
+        const bool wide = !ring && cout % 128 == 0;
+        a.tiles_n = cout / (wide ? 128 : 64);
+        const unsigned grid = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * tiles_b);
+#define VA_LAUNCH_F32(NT_, NB_)                                                      \
+    {                                                                                \
+        if (pool) k_conv3x3_dma_f32<NT_, true, NB_><<<grid, 256, 0, st>>>(a);        \
+        else k_conv3x3_dma_f32<NT_, false, NB_><<<grid, 256, 0, st>>>(a);            \
+    }
+        if (ring) VA_LAUNCH_F32(1, VA_RING)
+        else if (wide) VA_LAUNCH_F32(2, 1)
+        else VA_LAUNCH_F32(1, 1)
+#undef VA_LAUNCH_F32
+        VA_LAUNCH_CHECK();
+        return VA_OK;
+    }
+    // BK = 32 (whole 128-byte lines per pixel, half the barriers) was measured 5 % SLOWER than BK = 16 with register
+    // staging: its 72 KB of LDS per workgroup drops the occupancy from 3 to 2 workgroups per CU.
     // 128-channel tiles only where they still give every CU two workgroups (not the 14x14 layers at B = 32)
     const bool wide = cout % 128 == 0 && (long)(cout / 128) * a.tiles_x * a.tiles_y * tiles_b >= VA_WIDE_MIN;
     if (wide) {
@@ -791,9 +1012,9 @@ int launch_conv_ex(int hw, int cin_pad, int cout, const float* wp, const float* 
     return VA_OK;
 }
 
-int launch_conv(const ConvLayer& L, const float* in, float* out, int B, hipStream_t st)
+int launch_conv(const ConvLayer& L, const float* zeros, const float* in, float* out, int B, hipStream_t st)
 {
-    return launch_conv_ex(L.hw, L.cin_pad, L.cout, L.wp, L.bias, in, out, nullptr, 0, L.pool, B, st);
+    return launch_conv_ex(L.hw, L.cin_pad, L.cout, L.wp, L.bias, in, out, nullptr, 0, L.pool, B, zeros, st);
 }
 
 int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const __bf16* in, void* out, bool out_f32, int B, hipStream_t st)
@@ -908,9 +1129,9 @@ WsPlan plan_ws(const va_vgg16* m, int B)
 }  // namespace
 
 int va_conv3x3_f32(int hw, int cin_pad, int cout, const float* wp, const float* bias, const float* in, float* out,
-                   const float* mask, int linear, int pool, int B, hipStream_t st)
+                   const float* mask, int linear, int pool, int B, const float* zeros, hipStream_t st)
 {
-    return launch_conv_ex(hw, cin_pad, cout, wp, bias, in, out, mask, linear, pool != 0, B, st);
+    return launch_conv_ex(hw, cin_pad, cout, wp, bias, in, out, mask, linear, pool != 0, B, zeros, st);
 }
 
 int va_fc_f32(const float* A, const float* Wt, const float* bias, float* out, float* slab, int M, int N, int K, int relu, hipStream_t st)
@@ -965,12 +1186,16 @@ extern "C" int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_di
     m->ctx = ctx;
     m->c_in = c_in;
     m->dtype = dtype;
-    m->c_in_pad = dtype == VA_DTYPE_BF16 ? 64 : va_cdiv(c_in, 16) * 16;
+    m->c_in_pad = dtype == VA_DTYPE_BF16 ? 64 : va_cdiv(c_in, VA_CIN_ALIGN) * VA_CIN_ALIGN;
     m->n_classes = n_classes;
     m->desc_dim = desc_dim;
     int hw = 224, cin = c_in, cin_pad = m->c_in_pad;
     int rc = VA_OK;
     auto fail = [&](int code) { va_vgg16_destroy(m); return code; };
+    if (hipMalloc(&m->zeros_f32, 512 * sizeof(float)) != hipSuccess || hipMemsetAsync(m->zeros_f32, 0, 512 * sizeof(float), st) != hipSuccess) {
+        va_set_error("va_vgg16_create: hipMalloc failed for the zero line");
+        return fail(VA_ERR_HIP);
+    }
     if (const char* e = getenv("VA_BF16_VARIANT")) m->bf16_variant = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 0;  // tests only
     if (dtype == VA_DTYPE_BF16) {
         if (hipMalloc(&m->zeros, 256) != hipSuccess || hipMemsetAsync(m->zeros, 0, 256, st) != hipSuccess) {
@@ -1105,7 +1330,7 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
             k_nchw_to_nhwc_pad<float, float><<<pgrid, 256, 0, st>>>((const float*)x, act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
         VA_LAUNCH_CHECK();
         for (int i = 0; i < 13; ++i) {
-            if (int rc = launch_conv(m->conv[i], act[cur], act[cur ^ 1], B, st)) return rc;
+            if (int rc = launch_conv(m->conv[i], m->zeros_f32, act[cur], act[cur ^ 1], B, st)) return rc;
             cur ^= 1;
         }
     }

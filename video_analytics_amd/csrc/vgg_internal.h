@@ -33,9 +33,9 @@ struct va_vgg16 {
 
 // fp32 3x3 convolution (implicit GEMM on MFMA) of an NHWC tensor with explicit packed weights [cout][9*cin_pad]:
 // out = conv(in) + bias, then ReLU unless `linear`, then zeroed where mask[same index] <= 0 (mask may be NULL;
-// only without pooling), then 2x2 max-pooled when `pool`.
+// only without pooling), then 2x2 max-pooled when `pool`.  zeros: the model's zeros_f32 (>= 512 zero floats).
 int va_conv3x3_f32(int hw, int cin_pad, int cout, const float* wp, const float* bias, const float* in, float* out,
-                   const float* mask, int linear, int pool, int B, hipStream_t st);
+                   const float* mask, int linear, int pool, int B, const float* zeros, hipStream_t st);
 // out[M][N] = A[M][K] . Wt[N][K]^T + bias (+ReLU); slab: >= va_fc_slab_floats(M, N, K) floats of scratch
 int va_fc_f32(const float* A, const float* Wt, const float* bias, float* out, float* slab, int M, int N, int K, int relu, hipStream_t st);
 size_t va_fc_slab_floats(int M, int N, int K);
