@@ -237,6 +237,12 @@ int va_vgg16_train_step(va_vgg16* model, const void* x, int x_is_u8, const void*
  * [cout][cin][3][3], fc [out][in] (FC1's input CHW-major), biases [out] -- i.e. what model.state_dict() and
  * optimizer.state_dict()['state'][..]['momentum_buffer'] hold.
  */
+/* Debugging aid of the tests: byte offsets inside the training workspace -- out[0..12] the 13 conv outputs,
+ * out[13..25] the pooled maps (0 where a layer has no pool), out[26], out[27] the two gradient buffers,
+ * out[28] the gradient at the classifier input, out[29] the NHWC input (HOST array of 30).  With the
+ * environment variable VA_TRAIN_STOP_AT=i set, va_vgg16_train_step returns after the backward pass of conv
+ * layer i, leaving the gradient buffers as that layer left them. */
+int va_vgg16_train_plan(const va_vgg16* model, int batch, unsigned long long* out);
 int va_vgg16_export_state(va_vgg16* model, int which, void* const* conv_w, void* const* conv_b,
                           void* const* fc_w, void* const* fc_b, void* stream);
 int va_vgg16_import_state(va_vgg16* model, int which, const void* const* conv_w, const void* const* conv_b,

@@ -21,7 +21,7 @@ EXPORTS = [
     "va_flow_to_stack", "va_selftest_exact_math", "va_tvl1_profile_enable", "va_tvl1_profile_read",
     "va_meter_update", "va_meter_average", "va_linear_svm_predict",
     "va_vgg16_train_init", "va_vgg16_train_workspace_bytes", "va_vgg16_train_step",
-    "va_vgg16_export_state", "va_vgg16_import_state",
+    "va_vgg16_export_state", "va_vgg16_import_state", "va_vgg16_train_plan",
 ]
 
 
@@ -113,6 +113,8 @@ def lib():
     L.va_vgg16_train_workspace_bytes.restype = sz
     L.va_vgg16_train_step.argtypes = [vp, vp, ci, vp, ci, cf, cf, ctypes.c_ulonglong, vp, vp, vp, sz, vp]
     L.va_vgg16_train_step.restype = ci
+    L.va_vgg16_train_plan.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_ulonglong)]
+    L.va_vgg16_train_plan.restype = ci
     L.va_vgg16_export_state.argtypes = [vp, ci, pp, pp, pp, pp, vp]
     L.va_vgg16_export_state.restype = ci
     L.va_vgg16_import_state.argtypes = [vp, ci, pp, pp, pp, pp, vp]

@@ -915,22 +915,13 @@ constexpr bool kConvPool[13] = {false, true, false, true, false, false, true, fa
 
 namespace {
 
-constexpr long VA_WIDE_MIN = 512;  // workgroups
-#ifndef VA_RING
-#define VA_RING 3
-#endif
-#ifndef VA_RING_MAXGRID
-#define VA_RING_MAXGRID 1024
-#endif
-#ifndef VA_F32_CONV_DEFAULT
-#define VA_F32_CONV_DEFAULT 1
-#endif
-#ifndef VA_CIN_ALIGN
-#define VA_CIN_ALIGN 16
-#endif
-#ifndef VA_RING_MAXGRID_F32
-#define VA_RING_MAXGRID_F32 1024
-#endif
+// Tile / staging policy of the conv launches (measured on MI355X)
+constexpr long VA_WIDE_MIN = 512;           // register-staged fp32 kernel: 128-channel tiles from this many workgroups
+constexpr int VA_RING = 3;                  // depth of the LDS-DMA ring (two workgroups per CU)
+constexpr long VA_RING_MAXGRID = 1024;      // bf16: ring + 64-channel tiles below this many workgroups (the 14x14 layers)
+constexpr long VA_RING_MAXGRID_F32 = 1024;  // fp32: the same threshold (0 and 4096 measured 2-4 % slower)
+constexpr int VA_F32_CONV_DEFAULT = 1;      // 1: LDS-DMA fp32 kernel where Cin % 32 == 0; VA_F32_CONV=0 selects the register-staged one (A/B)
+constexpr int VA_CIN_ALIGN = 16;            // fp32 first-layer channel padding (3 -> 16: register-staged kernel; 20 -> 32: DMA kernel)
 
 void pick_brick(int W, int H, int B, int& lgTW, int& lgTH, int& TB)
 {
