@@ -130,15 +130,19 @@ __global__ void k_ce_fwd_bwd(const float* __restrict__ logits, const long long* 
 
 // ---------------------------------------------------------------- classifier backward ----------
 
-// dX[b][i] = sum_o dZ[b][o] * W[o][i]  (o ascending), then * scale where mask[b][i] > 0, else 0 (mask may be NULL).
-// One thread per column i keeps all BMAX batch rows in registers; dZ is staged in LDS as [o][b].
+// dX[b][i] = sum_o dZ[b][o] * W[o][i], then * scale where mask[b][i] > 0, else 0 (mask may be NULL).
+// A workgroup owns 64 columns i; its four 64-thread groups take the output rows o = 4q + g of every 64-row chunk
+// and keep all BMAX batch rows in registers (dZ staged in LDS as [o][b]); the four partial sums are added in
+// the fixed order g = 0..3 (deterministic).  25088 / 64 = 392 workgroups for FC1.
 template <int BMAX>
 __global__ void __launch_bounds__(256) k_fc_dx(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ dx,
                                                int B, int O, int I, const float* __restrict__ mask, float scale)
 {
     constexpr int OC = 64;
     __shared__ __attribute__((aligned(16))) float sdz[OC][BMAX];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float spart[3][BMAX][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
     float acc[BMAX];
 #pragma unroll
     for (int b = 0; b < BMAX; ++b) acc[b] = 0.0f;
@@ -151,7 +155,8 @@ __global__ void __launch_bounds__(256) k_fc_dx(const float* __restrict__ dz, con
         __syncthreads();
         if (i < I) {
             const int on = O - o0 < OC ? O - o0 : OC;
-            for (int oo = 0; oo < on; ++oo) {
+#pragma unroll 4
+            for (int oo = grp; oo < on; oo += 4) {
                 const float wv = w[(size_t)(o0 + oo) * I + i];
 #pragma unroll
                 for (int b4 = 0; b4 < BMAX / 4; ++b4) {
@@ -162,11 +167,16 @@ __global__ void __launch_bounds__(256) k_fc_dx(const float* __restrict__ dz, con
             }
         }
     }
-    if (i >= I) return;
+    if (grp > 0) {
+#pragma unroll
+        for (int b = 0; b < BMAX; ++b) spart[grp - 1][b][col] = acc[b];
+    }
+    __syncthreads();
+    if (grp != 0 || i >= I) return;
 #pragma unroll
     for (int b = 0; b < BMAX; ++b)
         if (b < B) {
-            float v = acc[b];
+            float v = ((acc[b] + spart[0][b][col]) + spart[1][b][col]) + spart[2][b][col];
             if (mask) v = mask[(size_t)b * I + i] > 0.0f ? v * scale : 0.0f;
             dx[(size_t)b * I + i] = v;
         }
@@ -354,18 +364,29 @@ __global__ void k_wgrad_reduce_sgd(const float* __restrict__ slab, float* __rest
     w[idx] = fmaf(-lr, nv, w[idx]);
 }
 
-// bias gradient, pass 1: part[blk][co] = sum of dy[p][co] over the block's pixel range (p ascending per thread row)
+// bias gradient, pass 1: part[blk][co] = sum of dy[p][co] over the block's pixel range.  256 threads = (256 / cw)
+// pixel rows x cw channels per pass over the channels; four independent partial sums per thread keep four loads
+// in flight; the combination order is fixed (deterministic).
 __global__ void __launch_bounds__(256) k_conv_bgrad_partial(const float* __restrict__ dy, float* __restrict__ part, long P, int Cout, long chunk)
 {
     __shared__ float red[256];
     const long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
-    const int rows = 256 / (Cout < 256 ? Cout : 256);  // pixel rows handled in parallel
     for (int c0 = 0; c0 < Cout; c0 += 256) {
         const int cw = Cout - c0 < 256 ? Cout - c0 : 256;
+        const int rows = 256 / cw;
         const int c = threadIdx.x % cw, r = threadIdx.x / cw;
-        float s = 0.0f;
-        if (r < rows)
-            for (long p = p0 + r; p < p1; p += rows) s += dy[p * Cout + c0 + c];
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        if (r < rows) {
+            long p = p0 + r;
+            for (; p + 3L * rows < p1; p += 4L * rows) {
+                s0 += dy[p * Cout + c0 + c];
+                s1 += dy[(p + rows) * Cout + c0 + c];
+                s2 += dy[(p + 2L * rows) * Cout + c0 + c];
+                s3 += dy[(p + 3L * rows) * Cout + c0 + c];
+            }
+            for (; p < p1; p += rows) s0 += dy[p * Cout + c0 + c];
+        }
+        float s = (s0 + s1) + (s2 + s3);
         red[threadIdx.x] = s;
         __syncthreads();
         if (r == 0) {
@@ -376,12 +397,20 @@ __global__ void __launch_bounds__(256) k_conv_bgrad_partial(const float* __restr
     }
 }
 
-__global__ void k_conv_bgrad_sgd(const float* __restrict__ part, int nblk, float* __restrict__ bias, float* __restrict__ vb, int Cout, float lr, float mu)
+// pass 2 + momentum SGD: 64 channels per workgroup, four 64-thread groups each add a quarter of the partials
+__global__ void __launch_bounds__(256) k_conv_bgrad_sgd(const float* __restrict__ part, int nblk, float* __restrict__ bias, float* __restrict__ vb,
+                                                        int Cout, float lr, float mu)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cout) return;
+    __shared__ float red[3][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + col;
     float g = 0.0f;
-    for (int i = 0; i < nblk; ++i) g += part[(size_t)i * Cout + c];
+    if (c < Cout)
+        for (int i = grp; i < nblk; i += 4) g += part[(size_t)i * Cout + c];
+    if (grp > 0) red[grp - 1][col] = g;
+    __syncthreads();
+    if (grp != 0 || c >= Cout) return;
+    g = ((g + red[0][col]) + red[1][col]) + red[2][col];
     const float nv = fmaf(mu, vb[c], g);
     vb[c] = nv;
     bias[c] = fmaf(-lr, nv, bias[c]);
@@ -459,7 +488,7 @@ struct TrainPlan {
     size_t x0, y[13], p[13], a_d[3], logits, dlogits, dd[3], da0, g[2], wt, slab, bpart, total;
 };
 
-constexpr int kBgradBlocks = 256;
+constexpr int kBgradBlocks = 1024;
 
 TrainPlan plan_train(const va_vgg16* m, int B)
 {
@@ -615,7 +644,7 @@ extern "C" int va_vgg16_train_step(va_vgg16* m, const void* x, int x_is_u8, cons
         const float* mask = l > 0 ? fin[l] : nullptr;  // fin[l] = post-dropout activation of layer l-1
         int rc = fc_backward_dispatch(B, [&](auto BM) {
             constexpr int bm = decltype(BM)::value;
-            k_fc_dx<bm><<<va_cdiv(I, 256), 256, 0, st>>>(dz[l], m->fcw[l], dxo[l], B, O, I, mask, 2.0f);
+            k_fc_dx<bm><<<va_cdiv(I, 64), 256, 0, st>>>(dz[l], m->fcw[l], dxo[l], B, O, I, mask, 2.0f);
             const int orows = 16;
             k_fc_wgrad_sgd<bm><<<dim3(va_cdiv(I, 256), va_cdiv(O, orows)), 256, (size_t)orows * bm * sizeof(float), st>>>(
                 dz[l], fin[l], m->fcw[l], m->fc_mom_w[l], B, O, I, orows, lr, momentum);
@@ -671,7 +700,7 @@ extern "C" int va_vgg16_train_step(va_vgg16* m, const void* x, int x_is_u8, cons
         const long bchunk = (a.P + kBgradBlocks - 1) / kBgradBlocks;
         const int nblk = (int)((a.P + bchunk - 1) / bchunk);
         k_conv_bgrad_partial<<<nblk, 256, 0, st>>>(dyr, F(T.bpart), a.P, L.cout, bchunk);
-        k_conv_bgrad_sgd<<<va_cdiv(L.cout, 256), 256, 0, st>>>(F(T.bpart), nblk, L.bias, L.mom_b, L.cout, lr, momentum);
+        k_conv_bgrad_sgd<<<va_cdiv(L.cout, 64), 256, 0, st>>>(F(T.bpart), nblk, L.bias, L.mom_b, L.cout, lr, momentum);
         if (i > 0) cur = 1 - cur;
         VA_LAUNCH_CHECK();
         if (const char* e = getenv("VA_TRAIN_STOP_AT"))  // debugging aid: leave the gradient buffers as layer i left them
