@@ -259,3 +259,48 @@ def test_checkpoint_and_performance_files(tmp_path):
     perf = str(tmp_path / "perf.csv")
     U.savePerformance(0.25, 3.5, perf); U.savePerformance(0.5, 2.5, perf)
     assert open(perf).read() == "0.25,3.5\n0.5,2.5\n"
+
+
+def _write_mjpeg_avi(path, frames, fourcc=b"MJPG"):
+    """Minimal RIFF/AVI writer (test fixture): one video stream, one '00dc' chunk per JPEG frame."""
+    import io
+    import struct
+    chunks = b""
+    for fr in frames:
+        buf = io.BytesIO()
+        fr.save(buf, format="JPEG", quality=95)
+        d = buf.getvalue()
+        chunks += b"00dc" + struct.pack("<I", len(d)) + d + (b"\0" if len(d) & 1 else b"")
+    movi = b"LIST" + struct.pack("<I", 4 + len(chunks)) + b"movi" + chunks
+    strh = b"strh" + struct.pack("<I", 56) + b"vids" + fourcc + b"\0" * 48
+    strl = b"LIST" + struct.pack("<I", 4 + len(strh)) + b"strl" + strh
+    hdrl = b"LIST" + struct.pack("<I", 4 + len(strl)) + b"hdrl" + strl
+    body = b"AVI " + hdrl + movi
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def test_frame_extraction_every_nth_frame_and_directory_layout(tmp_path):
+    from PIL import Image
+    root, save = tmp_path / "videos", tmp_path / "frames"
+    (root / "ApplyEyeMakeup").mkdir(parents=True)
+    frames = [Image.new("RGB", (32, 24), (10 * i, 255 - 10 * i, 5 * i)) for i in range(23)]
+    _write_mjpeg_avi(str(root / "ApplyEyeMakeup" / "v_ApplyEyeMakeup_g01_c01.avi"), frames)
+    got = U.extractEveryNthFrame(str(root / "ApplyEyeMakeup" / "v_ApplyEyeMakeup_g01_c01.avi"), 10)
+    assert len(got) == 3  # frames 0, 10, 20
+    assert abs(got[1].getpixel((5, 5))[0] - 100) <= 3 and abs(got[2].getpixel((5, 5))[0] - 200) <= 3
+    with pytest.raises(ValueError):
+        U.extractEveryNthFrame(str(root / "nope.avi"), 10)
+    lst = tmp_path / "list.txt"
+    lst.write_text("ApplyEyeMakeup/v_ApplyEyeMakeup_g01_c01.avi\n")
+    U.convertVideosToFrames(str(root), str(save), str(lst), mode="test")
+    d = save / "ApplyEyeMakeup" / "v_ApplyEyeMakeup_g01_c01"
+    assert sorted(os.listdir(str(d))) == ["0.jpg", "1.jpg", "2.jpg"]  # the names SpatialDataset opens
+    # an existing frame directory means "already converted": nothing is rewritten
+    os.remove(str(d / "2.jpg"))
+    U.convertVideosToFrames(str(root), str(save), str(lst), mode="test")
+    assert sorted(os.listdir(str(d))) == ["0.jpg", "1.jpg"]
+    # codecs without a decoder in this image fail loudly (UCF-101 itself is XviD)
+    _write_mjpeg_avi(str(root / "x.avi"), frames[:2], fourcc=b"XVID")
+    with pytest.raises(ValueError, match="XVID"):
+        U.extractEveryNthFrame(str(root / "x.avi"), 1)

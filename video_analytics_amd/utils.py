@@ -17,6 +17,7 @@ import random
 
 import numpy as np
 import torch
+from PIL import Image
 from torch.utils.data import DataLoader
 
 from .parameters import *  # noqa: F401,F403  (the reference star-imports its config the same way)
@@ -54,6 +55,77 @@ def multiStepLr(baseLr, milestones, lastEpoch, gamma=0.1):
     ``scheduler.step(...)`` -- the reference passes the validation LOSS (Sheet03/spatialModel.py:278, quirk)."""
     import bisect
     return baseLr * gamma ** bisect.bisect_right(sorted(milestones), lastEpoch)
+
+
+def iterVideoFrames(videoLoc):
+    """Decoded frames (PIL RGB images) of a video file, in order.  The reference decodes with ``cv2.VideoCapture``
+    (Sheet03/utils.py:57-68); OpenCV is not in this image, so the container is parsed here: RIFF/AVI with
+    Motion-JPEG streams (``MJPG``: every ``##dc`` / ``##db`` chunk of the ``movi`` list is one JPEG, decoded with
+    PIL).  Any other codec (UCF-101 ships XviD) raises ValueError naming its fourcc: there is no decoder for it
+    here."""
+    import io
+    import struct
+    with open(videoLoc, "rb") as f:
+        data = f.read()
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"AVI ":
+        raise ValueError("iterVideoFrames: %s is not a RIFF/AVI file" % videoLoc)
+    fourcc = None
+    k = data.find(b"strh")
+    while k >= 0:  # the video stream header: 'strh' <size> 'vids' <handler fourcc>
+        if data[k + 8:k + 12] == b"vids":
+            fourcc = data[k + 12:k + 16]
+            break
+        k = data.find(b"strh", k + 4)
+    if fourcc is None or fourcc.upper() not in (b"MJPG", b"JPEG"):
+        raise ValueError("iterVideoFrames: no decoder for video codec %r of %s in this image (OpenCV is absent; "
+                         "Motion-JPEG AVI files are supported)" % (fourcc, videoLoc))
+    k = data.find(b"movi")
+    if k < 0:
+        raise ValueError("iterVideoFrames: %s has no movi list" % videoLoc)
+    end = k - 4 + 8 + struct.unpack("<I", data[k - 4:k])[0]
+    k += 4
+    while k + 8 <= min(end, len(data)):
+        cid, size = data[k:k + 4], struct.unpack("<I", data[k + 4:k + 8])[0]
+        if cid == b"LIST":  # 'rec ' groups: descend
+            k += 12
+            continue
+        if cid[2:4] in (b"dc", b"db") and size > 0:
+            yield Image.open(io.BytesIO(data[k + 8:k + 8 + size])).convert("RGB")
+        k += 8 + size + (size & 1)
+
+
+def extractEveryNthFrame(videoLoc, N):
+    """Every N-th frame (0, N, 2N, ...) of the video at ``videoLoc`` (Sheet03/utils.py:51-69); ValueError if the
+    file does not exist."""
+    if not (os.path.exists(videoLoc) and os.path.isfile(videoLoc)):
+        raise ValueError("Video does not exist: %s" % (videoLoc))
+    frameList = []
+    for frameIdx, frame in enumerate(iterVideoFrames(videoLoc)):
+        if frameIdx % N == 0:
+            frameList.append(frame)
+    return frameList
+
+
+def convertVideosToFrames(rootDir, saveDir, videoListLoc, sampleRate=VIDEO_FRAME_SAMPLE_RATE, mode="train"):
+    """Sheet03/utils.py:95-121: every ``sampleRate``-th frame of each listed video goes to
+    ``saveDir/<category>/<videoName>/<i>.jpg`` (i = 0, 1, ... counts the SAMPLED frames: the names
+    ``SpatialDataset.__getitem__`` opens, Sheet03/spatialModel.py:75-77).  A video whose frame directory already
+    exists is skipped, like in the reference (it takes an existing directory as 'frames written already')."""
+    if not rootDir.endswith("/"):
+        rootDir = rootDir + "/"
+    if not saveDir.endswith("/"):
+        saveDir = saveDir + "/"
+    with open(videoListLoc, "r") as videoListFile:
+        for line in videoListFile:
+            videoLoc, videoName, _, actionCategory, _, _ = videoInfo(line, mode)
+            videoLoc = rootDir + videoLoc
+            frameDir = saveDir + actionCategory + "/" + videoName
+            if all(checkAndMakeDirectories(frameDir)):
+                continue
+            frameList = extractEveryNthFrame(videoLoc, sampleRate)
+            for i in range(len(frameList)):
+                frameList[i].save(frameDir + "/" + str(i) + FRAME_EXTN, quality=95)  # cv2.imwrite's default JPEG quality
+    return
 
 
 def videoInfo(line, mode):
