@@ -656,6 +656,8 @@ extern "C" int va_vgg16_train_step(va_vgg16* m, const void* x, int x_is_u8, cons
     VA_LAUNCH_CHECK();
 
     // ---------------- feature stack backward + update ----------------
+    const char* stop_env = getenv("VA_TRAIN_STOP_AT");
+    const int stop_at = stop_env ? atoi(stop_env) : -1;
     const float* dout = F(T.da0);  // gradient at layer 12's pooled output
     int cur = -1;                  // which of the two gradient buffers holds `dout` (-1: neither)
     for (int i = 12; i >= 0; --i) {
@@ -703,8 +705,7 @@ extern "C" int va_vgg16_train_step(va_vgg16* m, const void* x, int x_is_u8, cons
         k_conv_bgrad_sgd<<<va_cdiv(L.cout, 64), 256, 0, st>>>(F(T.bpart), nblk, L.bias, L.mom_b, L.cout, lr, momentum);
         if (i > 0) cur = 1 - cur;
         VA_LAUNCH_CHECK();
-        if (const char* e = getenv("VA_TRAIN_STOP_AT"))  // debugging aid: leave the gradient buffers as layer i left them
-            if (atoi(e) == i) return VA_OK;
+        if (stop_at == i) return VA_OK;  // debugging aid (VA_TRAIN_STOP_AT): leave the gradient buffers as layer i left them
     }
     return VA_OK;
 }
