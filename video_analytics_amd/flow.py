@@ -77,7 +77,8 @@ def tvl1_flow_concurrent(frames, params=None, n_streams=2):
     dev = frames.device
     key = (dev.index, n)
     if key not in _streams:
-        _streams[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        # high priority: their tile launches are dispatched ahead of anything that runs beside them (pipeline.py)
+        _streams[key] = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(n)]
     cur = torch.cuda.current_stream(dev)
     bounds = [(S * i) // n for i in range(n + 1)]
     outs = []
