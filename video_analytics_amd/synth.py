@@ -111,7 +111,7 @@ def _gauss_kernel1d(sigma):
 
 def _blur(img, sigma):
     """img [N,1,H,W] float32, separable Gaussian, reflect border."""
-    g = _gauss_kernel1d(sigma)
+    g = _gauss_kernel1d(sigma).to(img.device)
     r = (g.numel() - 1) // 2
     x = torch.nn.functional.pad(img, (r, r, r, r), mode="reflect")
     x = torch.nn.functional.conv2d(x, g.view(1, 1, 1, -1))
@@ -119,8 +119,11 @@ def _blur(img, sigma):
     return x
 
 
-def synth_clips(n_clips, seed=0, H=224, W=224, n_gray=11, first_clip=0):
-    """Synthetic clips of the benchmark's shape, on the CPU.
+def synth_clips(n_clips, seed=0, H=224, W=224, n_gray=11, first_clip=0, device="cpu"):
+    """Synthetic clips of the benchmark's shape, on the CPU (default: the
+    reproducible reference every test uses) or, with ``device="cuda"``, generated on the GPU from the same hash
+    streams (BASELINE config 4: no disk, no host generation in the sweep; filtering/resampling then run in the
+    device's arithmetic, so the bytes differ slightly from the CPU version).
 
     Returns (rgb uint8 [n,3,H,W], gray uint8 [n,n_gray,H,W], true_flow float32 [n,2,H,W]):
       * rgb: i.i.d. uniform noise, 3x3 box-blurred;
@@ -132,14 +135,19 @@ def synth_clips(n_clips, seed=0, H=224, W=224, n_gray=11, first_clip=0):
     """
     M = 24  # texture margin so that moved samples stay inside
     n = n_clips
+    dev = torch.device(device)
     Ht, Wt = H + 2 * M, W + 2 * M
-    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
-    u = torch.empty((n, 3, H, W), dtype=torch.float32)
-    t = torch.empty((n, 1, Ht, Wt), dtype=torch.float32)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=dev), torch.arange(W, dtype=torch.float32, device=dev), indexing="ij")
+    u = torch.empty((n, 3, H, W), dtype=torch.float32, device=dev)
+    t = torch.empty((n, 1, Ht, Wt), dtype=torch.float32, device=dev)
     ph = np.empty((n, 4), dtype=np.float32)
     for i, c in enumerate(range(first_clip, first_clip + n)):
-        u[i] = torch.from_numpy(hash_uniform(seed, 3 * c, 3 * H * W).reshape(3, H, W))
-        t[i, 0] = torch.from_numpy(hash_uniform(seed, 3 * c + 1, Ht * Wt).reshape(Ht, Wt))
+        if dev.type == "cpu":
+            u[i] = torch.from_numpy(hash_uniform(seed, 3 * c, 3 * H * W).reshape(3, H, W))
+            t[i, 0] = torch.from_numpy(hash_uniform(seed, 3 * c + 1, Ht * Wt).reshape(Ht, Wt))
+        else:
+            u[i] = hash_uniform_t(seed, 3 * c, 3 * H * W, device=dev).view(3, H, W)
+            t[i, 0] = hash_uniform_t(seed, 3 * c + 1, Ht * Wt, device=dev).view(Ht, Wt)
         ph[i] = hash_uniform(seed, 3 * c + 2, 4)
     box = torch.cat([torch.nn.functional.avg_pool2d(torch.nn.functional.pad(u[i:i + 1], (1, 1, 1, 1), mode="reflect"), 3, stride=1)
                      for i in range(n)], dim=0)
@@ -148,10 +156,10 @@ def synth_clips(n_clips, seed=0, H=224, W=224, n_gray=11, first_clip=0):
     tmin = t.amin(dim=(2, 3), keepdim=True)
     tmax = t.amax(dim=(2, 3), keepdim=True)
     t = (t - tmin) / (tmax - tmin) * 255.0
-    amp = torch.from_numpy(1.0 + 2.0 * ph[:, 0]).view(n, 1, 1)
-    dx = 1.5 + amp * torch.sin(2 * math.pi * (yy / H).unsqueeze(0) + 6.2831853 * torch.from_numpy(ph[:, 1]).view(n, 1, 1))
-    dy = -0.75 + amp * torch.cos(2 * math.pi * (xx / W).unsqueeze(0) + 6.2831853 * torch.from_numpy(ph[:, 2]).view(n, 1, 1))
-    gray = torch.empty((n, n_gray, H, W), dtype=torch.uint8)
+    amp = torch.from_numpy(1.0 + 2.0 * ph[:, 0]).view(n, 1, 1).to(dev)
+    dx = 1.5 + amp * torch.sin(2 * math.pi * (yy / H).unsqueeze(0) + 6.2831853 * torch.from_numpy(ph[:, 1]).view(n, 1, 1).to(dev))
+    dy = -0.75 + amp * torch.cos(2 * math.pi * (xx / W).unsqueeze(0) + 6.2831853 * torch.from_numpy(ph[:, 2]).view(n, 1, 1).to(dev))
+    gray = torch.empty((n, n_gray, H, W), dtype=torch.uint8, device=dev)
     for k in range(n_gray):
         sx = xx.unsqueeze(0) + M - k * dx
         sy = yy.unsqueeze(0) + M - k * dy
