@@ -30,11 +30,11 @@ def release_workspaces():
     _ws_cache.clear()
 
 
-def tvl1_flow(frames, params=None, ws_slot=0, **over):
+def tvl1_flow(frames, params=None, ws_slot=0, out=None, **over):
     """frames: cuda uint8 or float32 tensor ``[S, F, H, W]`` (or ``[F, H, W]``), gray values in [0,255].
 
-    Returns float32 ``[S*(F-1), 2, H, W]``: plane 0 = x flow, plane 1 = y flow of every consecutive
-    frame pair.  ``params``: ``_ffi.Tvl1Params`` or keyword overrides (tau, lambda_, theta, nscales,
+    Returns float32 ``[S*(F-1), 2, H, W]`` (written into ``out`` when given): plane 0 = x flow, plane 1 = y
+    flow of every consecutive frame pair.  ``params``: ``_ffi.Tvl1Params`` or keyword overrides (tau, lambda_, theta, nscales,
     warps, epsilon, iters, scale_step, block_iters).
     """
     if not isinstance(frames, torch.Tensor) or not frames.is_cuda:
@@ -54,7 +54,13 @@ def tvl1_flow(frames, params=None, ws_slot=0, **over):
     if nbytes == 0:
         raise ValueError(L.va_last_error().decode())
     ws = _workspace(nbytes, frames.device, ws_slot)
-    flow = torch.empty((S * (F - 1), 2, H, W), dtype=torch.float32, device=frames.device)
+    if out is None:
+        flow = torch.empty((S * (F - 1), 2, H, W), dtype=torch.float32, device=frames.device)
+    else:
+        flow = out
+        if (tuple(flow.shape) != (S * (F - 1), 2, H, W) or flow.dtype != torch.float32 or flow.device != frames.device
+                or not flow.is_contiguous()):
+            raise ValueError("tvl1_flow: out must be a contiguous float32 [%d,2,%d,%d] tensor on the frames' device" % (S * (F - 1), H, W))
     _ffi.check(L.va_tvl1_flow(c, _ffi.ptr(frames), int(frames.dtype == torch.uint8), S, F, W, H, ctypes.byref(p),
                               _ffi.ptr(flow), _ffi.ptr(ws), ws.numel(), _ffi.stream_ptr()))
     return flow
@@ -81,17 +87,18 @@ def tvl1_flow_concurrent(frames, params=None, n_streams=2):
         _streams[key] = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(n)]
     cur = torch.cuda.current_stream(dev)
     bounds = [(S * i) // n for i in range(n + 1)]
-    outs = []
+    F = frames.shape[1]
+    flow = torch.empty((S * (F - 1), 2, frames.shape[2], frames.shape[3]), dtype=torch.float32, device=dev)
     for i, st in enumerate(_streams[key]):
         st.wait_stream(cur)
         with torch.cuda.stream(st):
             part = frames[bounds[i]:bounds[i + 1]]
             part.record_stream(st)
-            outs.append(tvl1_flow(part, params, ws_slot=i + 1))
-    for st, o in zip(_streams[key], outs):
+            flow.record_stream(st)
+            tvl1_flow(part, params, ws_slot=i + 1, out=flow[bounds[i] * (F - 1):bounds[i + 1] * (F - 1)])
+    for st in _streams[key]:
         cur.wait_stream(st)
-        o.record_stream(cur)
-    return torch.cat(outs, dim=0)
+    return flow
 
 
 def flow_to_stack(flow, bound=FLOW_BOUND, mean=NORM_MEANS_TF[0], std=NORM_STDS_TF[0]):
