@@ -251,24 +251,29 @@ struct WgradArgs {
     int chunk;          // pixels per split (multiple of 16)
 };
 
-// 128 output channels x 128 (tap, input channel) columns per workgroup, K = a run of `chunk` pixels, 16 per step.
-// LDS tiles are pixel-major ([k][m], [k][n], stride 160 floats: the two k rows of an MFMA fragment read fall in
+// (WM*64) output channels x (WN*64) (tap, input channel) columns per workgroup of WM*WN = 4 waves (64 x 64 per wave:
+// 128 x 128, or 64 x 256 for the 64-channel layers), K = a run of `chunk` pixels, 16 per step.  LDS tiles are
+// pixel-major ([k][m], [k][n], row stride = width + 32 floats: the two k rows of an MFMA fragment read fall in
 // different bank halves), operands one float per lane for v_mfma_f32_32x32x2_f32.
+template <int WM, int WN>
 __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs a)
 {
-    constexpr int BK = 16, LS = 160;
-    __shared__ __attribute__((aligned(16))) float sA[2][BK * LS], sB[2][BK * LS];
+    constexpr int BK = 16, BM = WM * 64, BN = WN * 64, LSA = BM + 32, LSB = BN + 32;
+    constexpr int RA = 256 / (BM / 4), RB = 256 / (BN / 4);  // pixel rows one pass of the 256 loader threads covers
+    constexpr int A_PER = BK / RA, B_PER = BK / RB;          // float4 loads per thread and step
+    __shared__ __attribute__((aligned(16))) float sA[2][BK * LSA], sB[2][BK * LSB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const long p0 = (long)blockIdx.z * a.chunk;
     const long p1 = p0 + a.chunk < a.P ? p0 + a.chunk : a.P;
     const int H = a.H, Cout = a.Cout, cpad = a.cin_pad;
 
-    // loader role: float4 column c4 of pixel rows krow and krow + 8
-    const int c4 = (tid & 31) * 4, krow = tid >> 5;
-    const bool mok = m0 + c4 < Cout;
-    const int n = n0 + c4;
+    // loader roles: one float4 column per thread (fixed over the passes), pixel rows krow + R * i
+    const int ca4 = (tid % (BM / 4)) * 4, krowa = tid / (BM / 4);
+    const int cb4 = (tid % (BN / 4)) * 4, krowb = tid / (BN / 4);
+    const bool mok = m0 + ca4 < Cout;
+    const int n = n0 + cb4;
     const bool nok = n < a.N;
     const int kp = nok ? n / cpad : 0, ci = nok ? n - kp * cpad : 0;
     const int ky = kp / 3 - 1, kx = kp % 3 - 1;
@@ -281,31 +286,32 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    f32x4 ra[2], rb[2];
+    f32x4 ra[A_PER], rb[B_PER];
     auto gload = [&](long pbase) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const long p = pbase + krow + 8 * i;
+        for (int i = 0; i < A_PER; ++i) {
+            const long p = pbase + krowa + RA * i;
             ra[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (p < p1 && mok) ra[i] = *reinterpret_cast<const f32x4*>(a.dy + p * Cout + m0 + ca4);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const long p = pbase + krowb + RB * i;
             rb[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (p < p1) {
-                if (mok) ra[i] = *reinterpret_cast<const f32x4*>(a.dy + p * Cout + m0 + c4);
-                if (nok) {
-                    const int x = (int)(p % H);
-                    const long r = p / H;
-                    const int y = (int)(r % H);
-                    const int yy = y + ky, xx = x + kx;
-                    if (yy >= 0 && yy < H && xx >= 0 && xx < H) rb[i] = *reinterpret_cast<const f32x4*>(a.x + (p + (long)ky * H + kx) * cpad + ci);
-                }
+            if (p < p1 && nok) {
+                const int x = (int)(p % H);
+                const long r = p / H;
+                const int y = (int)(r % H);
+                const int yy = y + ky, xx = x + kx;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < H) rb[i] = *reinterpret_cast<const f32x4*>(a.x + (p + (long)ky * H + kx) * cpad + ci);
             }
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<f32x4*>(&sA[buf][(krow + 8 * i) * LS + c4]) = ra[i];
-            *reinterpret_cast<f32x4*>(&sB[buf][(krow + 8 * i) * LS + c4]) = rb[i];
-        }
+        for (int i = 0; i < A_PER; ++i) *reinterpret_cast<f32x4*>(&sA[buf][(krowa + RA * i) * LSA + ca4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) *reinterpret_cast<f32x4*>(&sB[buf][(krowb + RB * i) * LSB + cb4]) = rb[i];
     };
 
     const int r31 = lane & 31, hh = lane >> 5;
@@ -323,8 +329,8 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs a)
             float fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                fa[i] = sA[buf][(2 * ks + hh) * LS + (wm * 2 + i) * 32 + r31];
-                fb[i] = sB[buf][(2 * ks + hh) * LS + (wn * 2 + i) * 32 + r31];
+                fa[i] = sA[buf][(2 * ks + hh) * LSA + (wm * 2 + i) * 32 + r31];
+                fb[i] = sB[buf][(2 * ks + hh) * LSB + (wn * 2 + i) * 32 + r31];
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -460,7 +466,7 @@ __global__ void k_repack_fc1(const float* __restrict__ w, float* __restrict__ wp
 // ---------------------------------------------------------------- host side --------------------
 
 struct WgradPlan {
-    int Mpad, Npad, S, chunk;
+    int BM, BN, Mpad, Npad, S, chunk;
     size_t slab_floats;
 };
 
@@ -468,10 +474,12 @@ WgradPlan plan_wgrad(int B, int hw, int cout, int cin_pad)
 {
     WgradPlan p;
     const int N = 9 * cin_pad;
-    p.Mpad = va_cdiv(cout, 128) * 128;
-    p.Npad = va_cdiv(N, 128) * 128;
+    p.BM = cout <= 64 ? 64 : 128;  // 64 x 256 tiles for the 64-channel layers, 128 x 128 otherwise
+    p.BN = cout <= 64 ? 256 : 128;
+    p.Mpad = va_cdiv(cout, p.BM) * p.BM;
+    p.Npad = va_cdiv(N, p.BN) * p.BN;
     const long P = (long)B * hw * hw;
-    const int tiles = (p.Mpad / 128) * (p.Npad / 128);
+    const int tiles = (p.Mpad / p.BM) * (p.Npad / p.BN);
     long S = va_cdiv(2048, tiles);  // aim for ~2048 workgroups
     const long maxS = P / 256 > 0 ? P / 256 : 1;
     if (S > maxS) S = maxS;
@@ -696,7 +704,8 @@ extern "C" int va_vgg16_train_step(va_vgg16* m, const void* x, int x_is_u8, cons
         a.Mpad = wp.Mpad;
         a.P = (long)B * L.hw * L.hw;
         a.chunk = wp.chunk;
-        k_conv_wgrad<<<dim3(wp.Npad / 128, wp.Mpad / 128, wp.S), 256, 0, st>>>(a);
+        if (wp.BM == 64) k_conv_wgrad<1, 4><<<dim3(wp.Npad / 256, wp.Mpad / 64, wp.S), 256, 0, st>>>(a);
+        else k_conv_wgrad<2, 2><<<dim3(wp.Npad / 128, wp.Mpad / 128, wp.S), 256, 0, st>>>(a);
         const size_t nw = (size_t)L.cout * a.N;
         k_wgrad_reduce_sgd<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(slab, L.wp, L.mom_w, L.cout, a.N, wp.Mpad, wp.Npad, wp.S, lr, momentum);
         const long bchunk = (a.P + kBgradBlocks - 1) / kBgradBlocks;
