@@ -140,6 +140,11 @@ void va_tvl1_default_params(va_tvl1_params* p);
 /* Number of pyramid levels actually used and their sizes (ws/hs: HOST arrays of >= 16 ints). */
 int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* hs);
 
+/* The register tiling va_tvl1_flow will use, level by level (host logic; HOST array of >= 6*16 ints): per level
+ * { tile width, tile height, waves per workgroup, block depth K, tiles in x, tiles in y }.  Returns the number
+ * of levels (0 on bad arguments). */
+int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out);
+
 size_t va_tvl1_workspace_bytes(int w, int h, int n_seq, int frames_per_seq, const va_tvl1_params* p);
 
 /*

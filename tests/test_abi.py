@@ -63,3 +63,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), os.path.join(dp, f)
+
+
+def test_tile_plan_of_the_benchmark_pyramid():
+    """Host-side tiling logic of va_tvl1_flow (no GPU needed): the plan documented in profiles/README.md for the
+    224x224 benchmark pyramid in fixed-iteration mode, and the epsilon mode's forced block depth 1."""
+    from video_analytics_amd import _ffi, flow
+    plan = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0))
+    assert [(d["tile_w"], d["tile_h"], d["waves"], d["block_iters"]) for d in plan] == [
+        (128, 64, 8, 12), (64, 64, 4, 12), (84, 48, 4, 8), (128, 64, 8, 7), (64, 64, 4, 16)]
+    assert [(d["tiles_x"], d["tiles_y"]) for d in plan] == [(2, 5), (4, 4), (2, 4), (1, 2), (2, 2)]
+    for d, n in zip(plan, (224, 179, 143, 114, 91)):  # the valid regions of the tiles cover the level
+        hx = -(-d["block_iters"] // 4) * 4 if d["tiles_x"] > 1 else 0
+        assert d["tiles_x"] * d["tile_w"] - 2 * hx * (d["tiles_x"] - 1) >= n
+        hy = d["block_iters"] if d["tiles_y"] > 1 else 0
+        assert d["tiles_y"] * d["tile_h"] - 2 * hy * (d["tiles_y"] - 1) >= n
+    assert all(d["block_iters"] == 1 for d in flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.01)))
+    forced = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, block_iters=6, tile_mask=1 << 5))
+    assert all((d["tile_w"], d["tile_h"], d["block_iters"]) == (128, 32, 6) for d in forced)

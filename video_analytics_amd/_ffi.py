@@ -17,7 +17,7 @@ EXPORTS = [
     "va_version", "va_last_error", "va_ctx_create", "va_ctx_destroy",
     "va_vgg16_create", "va_vgg16_destroy", "va_vgg16_workspace_bytes", "va_vgg16_forward", "va_vgg16_classify",
     "va_copy_first_layer", "va_validate_batch",
-    "va_tvl1_default_params", "va_tvl1_pyramid_sizes", "va_tvl1_workspace_bytes", "va_tvl1_flow",
+    "va_tvl1_default_params", "va_tvl1_pyramid_sizes", "va_tvl1_tile_plan", "va_tvl1_workspace_bytes", "va_tvl1_flow",
     "va_flow_to_stack", "va_selftest_exact_math", "va_tvl1_profile_enable", "va_tvl1_profile_read",
     "va_meter_update", "va_meter_average", "va_linear_svm_predict",
     "va_vgg16_train_init", "va_vgg16_train_workspace_bytes", "va_vgg16_train_step",
@@ -89,6 +89,8 @@ def lib():
     L.va_tvl1_default_params.restype = None
     L.va_tvl1_pyramid_sizes.argtypes = [ci, ci, ctypes.POINTER(Tvl1Params), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.va_tvl1_pyramid_sizes.restype = ci
+    L.va_tvl1_tile_plan.argtypes = [ci, ci, ctypes.POINTER(Tvl1Params), ctypes.POINTER(ci)]
+    L.va_tvl1_tile_plan.restype = ci
     L.va_tvl1_workspace_bytes.argtypes = [ci, ci, ci, ci, ctypes.POINTER(Tvl1Params)]
     L.va_tvl1_workspace_bytes.restype = sz
     L.va_tvl1_flow.argtypes = [vp, vp, ci, ci, ci, ci, ci, ctypes.POINTER(Tvl1Params), vp, vp, sz, vp]

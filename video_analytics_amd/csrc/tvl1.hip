@@ -844,6 +844,28 @@ extern "C" int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int*
     return pyramid_sizes(w, h, p, ws, hs);
 }
 
+// The register tiling va_tvl1_flow will use (host logic only; no device needed): for every pyramid level s,
+// out[6*s .. 6*s+5] = { tile width, tile height, waves per workgroup, block depth K, tiles in x, tiles in y }.
+extern "C" int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out)
+{
+    if (!p || !out || w < 16 || h < 16 || !(p->scale_step > 0.0f && p->scale_step < 1.0f) || p->iters < 1) return 0;
+    int ws[kMaxScales], hs[kMaxScales];
+    const int ns = pyramid_sizes(w, h, p, ws, hs);
+    int K0 = p->block_iters;
+    if (p->epsilon > 0.0f) K0 = 1;
+    for (int s = 0; s < ns; ++s) {
+        const TilePick tp = K0 > 0 ? pick_tiles(ws[s], hs[s], K0, (unsigned)p->tile_mask) : pick_tiles_auto(ws[s], hs[s], p->iters, (unsigned)p->tile_mask);
+        const TileCfg& c = kCfgs[tp.cfg];
+        out[6 * s + 0] = c.LX * c.R;
+        out[6 * s + 1] = c.NW * (64 / c.LX) * c.C;
+        out[6 * s + 2] = c.NW;
+        out[6 * s + 3] = tp.K;
+        out[6 * s + 4] = tp.ntx;
+        out[6 * s + 5] = tp.nty;
+    }
+    return ns;
+}
+
 extern "C" size_t va_tvl1_workspace_bytes(int w, int h, int n_seq, int frames_per_seq, const va_tvl1_params* p)
 {
     if (check_params(p, w, h, n_seq, frames_per_seq) != VA_OK) return 0;

@@ -125,6 +125,16 @@ def pyramid_sizes(w, h, params=None):
     return [(ws[i], hs[i]) for i in range(n)]
 
 
+def tile_plan(w, h, params=None):
+    """The register tiling ``tvl1_flow`` will use per pyramid level (host logic, no GPU needed):
+    list of dict(tile_w, tile_h, waves, block_iters, tiles_x, tiles_y)."""
+    p = params if params is not None else _ffi.default_tvl1_params()
+    out = (ctypes.c_int * 96)()
+    n = _ffi.lib().va_tvl1_tile_plan(w, h, ctypes.byref(p), out)
+    keys = ("tile_w", "tile_h", "waves", "block_iters", "tiles_x", "tiles_y")
+    return [dict(zip(keys, [out[6 * s + k] for k in range(6)])) for s in range(n)]
+
+
 def profile_enable(on=True, device=None):
     _ffi.check(_ffi.lib().va_tvl1_profile_enable(_ffi.ctx(device), int(bool(on))))
 
