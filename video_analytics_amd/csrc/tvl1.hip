@@ -642,8 +642,8 @@ double tile_iter_us(int cfg)
     const double t = kCfgs[cfg].NW == 8 ? 2.63 : 1.2;
     return kCfgs[cfg].LX >= 32 ? t : 1.1 * t;  // 3- and 4-fold waves: a little slower
 }
-// A launch cannot beat the HBM stream of its tiles: ~5.2 TB/s measured = 20.3 kB per us per CU.
-double tile_hbm_us(int TW, int TH, int HX, int K) { return ((double)TW * TH * 40.0 + (double)(TW - 2 * HX) * (TH - 2 * K) * 24.0) / 20300.0; }
+// A launch cannot beat the HBM stream of its tiles: 4.5 TB/s = 17.6 kB per us per CU (5.2 TB/s is the best this access pattern reaches).
+double tile_hbm_us(int TW, int TH, int HX, int K) { return ((double)TW * TH * 40.0 + (double)(TW - 2 * HX) * (TH - 2 * K) * 24.0) / 17600.0; }
 double tile_cost_us(int cfg, int HX, int K)
 {
     const int TW = kCfgs[cfg].LX * kCfgs[cfg].R, TH = kCfgs[cfg].NW * (64 / kCfgs[cfg].LX) * kCfgs[cfg].C;
