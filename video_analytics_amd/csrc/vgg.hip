@@ -193,6 +193,22 @@ struct ConvArgs {
     const float* zeros; // DMA kernel: >= 16 zero bytes, the source of every out-of-image tap
 };
 
+#ifndef VA_XCD_REMAP
+#define VA_XCD_REMAP 1
+#endif
+// XCD-aware workgroup order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so
+// the channel tiles of one pixel tile and its neighbours (which share the A operand and its halo) would land on
+// different L2s.  This bijective remap gives every XCD a contiguous run of tiles instead.
+__device__ __forceinline__ int xcd_remap(unsigned bid, unsigned nb)
+{
+#if VA_XCD_REMAP
+    const unsigned q = nb / 8, r = nb % 8, xcd = bid % 8, k = bid / 8;
+    return (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k);
+#else
+    return (int)bid;
+#endif
+}
+
 __device__ __forceinline__ void brick_coords(int m, int lgTW, int lgTH, int& xl, int& yl, int& bl)
 {
     const int x0 = m & 1, y0 = (m >> 1) & 1;
@@ -221,7 +237,7 @@ __global__ void __launch_bounds__(WM * WN * 64) k_conv3x3_mfma(ConvArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int n_tile = bid % a.tiles_n;
     bid /= a.tiles_n;
     const int tile_x = bid % a.tiles_x;
@@ -429,7 +445,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) k_conv3x3_mfma_bf16(Co
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int n_tile = bid % a.tiles_n;
     bid /= a.tiles_n;
     const int tile_x = bid % a.tiles_x;
@@ -612,7 +628,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) k_conv3x3_dma_f32(Conv
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int n_tile = bid % a.tiles_n;
     bid /= a.tiles_n;
     const int tile_x = bid % a.tiles_x;
