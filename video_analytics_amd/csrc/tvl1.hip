@@ -398,21 +398,27 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
     __shared__ __attribute__((aligned(16))) float sP12[NG + 2][TW], sP22[NG + 2][TW], sU1[NG + 2][TW], sU2[NG + 2][TW];
     __shared__ unsigned long long sErr;
 
-    const int pair = blockIdx.y;
+    // XCD-aware workgroup order: the tiles of a pair (which share their halos) on one XCD's L2
+    unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const unsigned nb = gridDim.x * gridDim.y, q = nb / 8, r = nb % 8, xcd = lid % 8, kk = lid / 8;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+    }
+    const int pair = (int)(lid / gridDim.x), bx = (int)(lid % gridDim.x);
     int inbuf = a.cur;
     if constexpr (EPS) {
         // S7: a pair that met the stopping rule at iteration it-1 (or earlier: its later
         // counters stay 0 < qthr) does nothing more in this warp.
         if (a.it > 0 && a.err[(size_t)pair * a.iters + a.it - 1] < a.qthr) return;
         inbuf = a.base[pair] ^ (a.it & 1);
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.sel[pair] = inbuf ^ 1;
+        if (bx == 0 && threadIdx.x == 0) a.sel[pair] = inbuf ^ 1;
         if (threadIdx.x == 0) sErr = 0ull;
     }
     const int l64 = threadIdx.x & 63;
     const bool idle = l64 / LX >= GPW;                                     // lanes beyond the last whole row group
     const int lane = idle ? 0 : l64 % LX;                                  // position along x
     const int wave = idle ? NG : (int)(threadIdx.x >> 6) * GPW + l64 / LX;  // row group
-    const int tx = blockIdx.x % a.ntx, ty = blockIdx.x / a.ntx;
+    const int tx = bx % a.ntx, ty = bx / a.ntx;
     const int w = a.w, h = a.h, pitch = a.pitch, K = a.K;
     const int ox = tx * (TW - 2 * a.HX), oy = ty * (TH - 2 * K);
     const int vx0 = ox + (tx > 0 ? a.HX : 0), vx1 = (tx == a.ntx - 1) ? w : ox + TW - a.HX;
