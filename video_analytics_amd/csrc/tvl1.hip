@@ -295,6 +295,7 @@ struct IterArgs {
     int K;    // iterations in this launch
     int ntx, nty, HX;
     int it, iters;
+    int rev;  // odd launches walk the workgroup order backwards: what the previous launch wrote last is read first
     float l_t, taut, theta;
 };
 
@@ -308,6 +309,9 @@ __device__ __forceinline__ float dpp_from_right(float v)  // lane i <- lane i+1,
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+#ifndef VA_REV
+#define VA_REV 1
+#endif
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f32
 // a - b as one v_sub_f32 the vectoriser cannot re-pack (see the x differences in k_iter_tile)
@@ -403,6 +407,7 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
     {
         const unsigned nb = gridDim.x * gridDim.y, q = nb / 8, r = nb % 8, xcd = lid % 8, kk = lid / 8;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+        if (a.rev) lid = nb - 1 - lid;
     }
     const int pair = (int)(lid / gridDim.x), bx = (int)(lid % gridDim.x);
     int inbuf = a.cur;
@@ -993,6 +998,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                 a.cur = cur;
                 a.K = tk.K;
                 a.it = it;
+                a.rev = VA_REV ? (launches & 1) : 0;
                 if (eps) {
                     if (p->fast_math) launch_iter<true, true>(tk, a, P.NP, st);
                     else launch_iter<true, false>(tk, a, P.NP, st);
