@@ -81,3 +81,17 @@ def test_tile_plan_of_the_benchmark_pyramid():
     assert all(d["block_iters"] == 1 for d in flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.01)))
     forced = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, block_iters=6, tile_mask=1 << 5))
     assert all((d["tile_w"], d["tile_h"], d["block_iters"]) == (128, 32, 6) for d in forced)
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/va.h is a C ABI: it must compile as C99 (no C++ or torch types) with the system compiler."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    src = tmp_path / "t.c"
+    src.write_text('#include "va.h"\nint main(void) { va_tvl1_params p; va_tvl1_default_params(&p); return va_version() > 0 ? 0 : 1; }\n')
+    r = subprocess.run([cc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                        "-o", str(tmp_path / "t.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
