@@ -10,6 +10,9 @@
   * vgg_small.npz    class scores / descriptors / per-layer fp64 checksums of the torch-CPU oracle
                      (oracle/vgg_oracle.py) for both streams on 4 synthetic clips with the synthetic
                      weights of video_analytics_amd/synth.py (seeds 1 and 2).
+  * train_small.npz  two momentum-SGD steps of the autograd oracle (oracle/train_oracle.py) on 2 synthetic clips:
+                     losses, hits, descriptors and the updated classifier head (101 x 256) after each step.
+  * fusion_small.npz a fixed LinearSVC.predict problem: descriptors, coefficients, sequential-f64 scores, labels.
   * reference_parameters.json  the 43 config constants of Sheet03/parameters.py (names + values).
   * demoTest.txt / demoTrain.txt are the reference's own video lists (data fixtures, copied
     verbatim from /root/reference/Sheet03/).
@@ -24,7 +27,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-from oracle import tvl1_oracle, vgg_oracle  # noqa: E402
+from oracle import fusion_oracle, train_oracle, tvl1_oracle, vgg_oracle  # noqa: E402
 from video_analytics_amd import synth  # noqa: E402
 
 
@@ -75,6 +78,35 @@ def vgg():
     np.savez_compressed(os.path.join(HERE, "vgg_small.npz"), **res)
 
 
+def train():
+    w = synth.synth_vgg16_weights(c_in=3, seed=4)
+    ora = train_oracle.TrainOracle(w, 1e-4, 0.9)
+    res = {}
+    for step in range(2):
+        u = synth.hash_uniform(70 + step, 3, 2 * 3 * 224 * 224).reshape(2, 3, 224, 224)
+        x = torch.from_numpy(u * 4.0 - 2.0)
+        labels = torch.tensor([(7 * i + 3 * step + 1) % 101 for i in range(2)], dtype=torch.int64)
+        loss, corr, desc, _ = ora.step(x, labels, seed=1000 + step)
+        res["loss_%d" % step] = np.float32(loss)
+        res["hits_%d" % step] = np.int32(corr)
+        res["desc_%d" % step] = desc.numpy()
+        res["head_w_%d" % step] = ora.weights()["fc_w"][3].numpy()
+        res["head_mom_%d" % step] = ora.momentum()["fc_w"][3].numpy()
+        print("train step", step, "loss", loss, "hits", corr)
+    np.savez_compressed(os.path.join(HERE, "train_small.npz"), **res)
+
+
+def fusion():
+    x = synth.hash_uniform(200, 0, 40 * 512).reshape(40, 512).astype(np.float64) * 2 - 1
+    coef = synth.hash_uniform(200, 1, 25 * 512).reshape(25, 512).astype(np.float64) - 0.5
+    icpt = synth.hash_uniform(200, 2, 25).astype(np.float64) * 0.1
+    classes = np.arange(1, 26)
+    scores = fusion_oracle.linear_svm_scores(x, coef, icpt)
+    np.savez_compressed(os.path.join(HERE, "fusion_small.npz"), x=x, coef=coef, intercept=icpt, classes=classes, scores=scores,
+                        pred=fusion_oracle.linear_svm_predict(x, coef, icpt, classes))
+    print("fusion: predictions", np.bincount(scores.argmax(1), minlength=25).tolist())
+
+
 def reference_parameters():
     """Names and values of the reference's config constants (Sheet03/parameters.py imports cleanly under
     Python 3: SURVEY.md section 8c) -> reference_parameters.json.  Data, not source."""
@@ -97,3 +129,5 @@ if __name__ == "__main__":
     reference_parameters()
     tvl1()
     vgg()
+    train()
+    fusion()

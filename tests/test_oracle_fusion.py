@@ -40,3 +40,11 @@ def test_meter_bank_equals_the_average_meter_loop():
     for n, m in meters.items():
         assert bank[n][1] == m.count
         assert np.array_equal(bank[n][0], m.sum.numpy()) and np.array_equal(bank[n][2], m.avg.numpy())
+
+
+def test_fusion_oracle_reproduces_the_committed_golden():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fusion_small.npz"))
+    s = fusion_oracle.linear_svm_scores(g["x"], g["coef"], g["intercept"])
+    assert np.array_equal(s, g["scores"])
+    assert np.array_equal(fusion_oracle.linear_svm_predict(g["x"], g["coef"], g["intercept"], g["classes"]), g["pred"])

@@ -74,3 +74,20 @@ def test_goldens():
         assert np.abs(desc.numpy() - g["desc_" + name][:2]).max() < 1e-4
         # the fp32 oracle is itself within ~3e-5 of fp64 on these inputs
         assert np.abs(g["logits_" + name][:1] - g["logits64_" + name]).max() < 1e-4
+
+
+def test_training_oracle_reproduces_the_committed_golden():
+    """First step of tests/golden/train_small.npz (autograd + torch.optim.SGD on 2 clips): pins the oracle to history."""
+    import os
+    import numpy as np
+    from oracle import train_oracle
+    from video_analytics_amd import synth
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_small.npz"))
+    ora = train_oracle.TrainOracle(synth.synth_vgg16_weights(c_in=3, seed=4), 1e-4, 0.9)
+    x = torch.from_numpy(synth.hash_uniform(70, 3, 2 * 3 * 224 * 224).reshape(2, 3, 224, 224) * 4.0 - 2.0)
+    loss, corr, desc, _ = ora.step(x, torch.tensor([1, 8], dtype=torch.int64), seed=1000)
+    assert abs(loss - float(g["loss_0"])) < 1e-4 * abs(float(g["loss_0"])) and corr == int(g["hits_0"])
+    assert float((desc - torch.from_numpy(g["desc_0"])).abs().max()) < 1e-4 * float(np.abs(g["desc_0"]).max())
+    upd, ref = ora.weights()["fc_w"][3].numpy(), g["head_w_0"]
+    assert np.abs(upd - ref).max() < 1e-6

@@ -238,3 +238,27 @@ def test_activation_gradients_layer_by_layer(layer, monkeypatch):
     # (layer 4 measured: identical sparsity pattern, 0.08 % of the elements beyond 1e-2 -- the receptive field of the
     # two windows that flipped at conv4_3)
     assert best[0] <= 64 and best[1] <= (max(64, n // 10000) if layer >= 9 else n // 500), best
+
+
+def test_training_step_against_the_committed_golden():
+    """tests/golden/train_small.npz (two autograd steps on 2 clips, lr 1e-4, momentum 0.9): the first step's loss,
+    hits, train-mode descriptors, updated classifier head and its momentum buffer; the second step's loss only
+    loosely (two fp32 trajectories after one update of a random-init network)."""
+    import os
+    from video_analytics_amd import synth, vgg
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_small.npz"))
+    w = synth.synth_vgg16_weights(c_in=3, seed=4)
+    m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256)
+    for step in range(2):
+        x = torch.from_numpy(synth.hash_uniform(70 + step, 3, 2 * 3 * 224 * 224).reshape(2, 3, 224, 224) * 4.0 - 2.0)
+        labels = torch.tensor([(7 * i + 3 * step + 1) % 101 for i in range(2)], dtype=torch.int64)
+        stats, desc = m.train_step(x.cuda(), labels.cuda(), 1e-4, 0.9, 1000 + step)
+        loss_r = float(g["loss_%d" % step])
+        assert abs(float(stats[0]) - loss_r) < (2e-4 if step == 0 else 5e-3) * loss_r, (step, float(stats[0]), loss_r)
+        if step == 0:
+            assert int(stats[1]) == int(g["hits_0"])
+            assert _relerr(desc.cpu(), torch.from_numpy(g["desc_0"])) < 1e-3
+            head = m.export_state()["fc_w"][3].cpu()
+            assert _relerr(head - w["fc_w"][3], torch.from_numpy(g["head_w_0"]) - w["fc_w"][3]) < 5e-4
+            assert _relerr(m.export_state(momentum=True)["fc_w"][3].cpu(), torch.from_numpy(g["head_mom_0"])) < 5e-4
+    m.close()
