@@ -177,8 +177,14 @@ __global__ void k_warp(const float* __restrict__ pyr, size_t plane, int w, int h
                        const float* __restrict__ stA, const float* __restrict__ stB, const int* __restrict__ sel, int cur,
                        int* __restrict__ base, float* __restrict__ ro, int pair0)
 {
-    const int pair = pair0 + blockIdx.y;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware workgroup order (as in k_iter_tile): the pixel blocks of a pair gather from one L2
+    unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const unsigned nb = gridDim.x * gridDim.y, q = nb / 8, r = nb % 8, xcd = lid % 8, kk = lid / 8;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+    }
+    const int pair = pair0 + (int)(lid / gridDim.x);
+    const int idx = (int)(lid % gridDim.x) * blockDim.x + threadIdx.x;
     const int which = sel ? sel[pair] : cur;
     if (base && idx == 0) base[pair] = which;
     const bool active = idx < w * h;  // inactive lanes still take part in the shuffles
