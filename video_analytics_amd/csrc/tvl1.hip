@@ -655,13 +655,14 @@ struct TilePick {
 // Cost of a workgroup in CU-microseconds, measured on MI355X (tools/bench_tvl1_levels.py,
 // tools/microbench_tvl1_tile.py): exposed HBM round trip per launch + time per inner iteration.
 // The 4-wave candidates (half-size tiles) run two workgroups per CU: one's load/store phase hides
-// behind the other's arithmetic (3.3 us exposed per 4096-pixel tile instead of 14.4 us per 8192) and
-// the 4-wave barriers cost less (1.2 us per iteration instead of 2.63 / 2).
-double tile_launch_us(int cfg) { return kCfgs[cfg].NW == 8 ? 14.4 : 3.3; }
+// behind the other's arithmetic (a few us exposed per 4096-pixel tile instead of ~15 us per 8192) and
+// the 4-wave barriers cost less (1.2 us per iteration instead of ~2.7 / 2).  The constants are fitted to the
+// per-level optimum found by brute force with the cache-aware workgroup order in place (tools/sweep in profiles/README.md).
+double tile_launch_us(int cfg) { return kCfgs[cfg].NW == 8 ? 17.0 : 4.5; }
 double tile_iter_us(int cfg)
 {
-    const double t = kCfgs[cfg].NW == 8 ? 2.63 : 1.2;
-    return kCfgs[cfg].LX >= 32 ? t : 1.1 * t;  // 3- and 4-fold waves: a little slower
+    const double t = kCfgs[cfg].NW == 8 ? 2.75 : 1.2;
+    return kCfgs[cfg].LX >= 32 ? t : 1.03 * t;  // 3- and 4-fold waves: a little slower
 }
 // A launch cannot beat the HBM stream of its tiles: 4.5 TB/s = 17.6 kB per us per CU (5.2 TB/s is the best this access pattern reaches).
 double tile_hbm_us(int TW, int TH, int HX, int K) { return ((double)TW * TH * 40.0 + (double)(TW - 2 * HX) * (TH - 2 * K) * 24.0) / 17600.0; }
