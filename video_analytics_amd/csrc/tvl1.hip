@@ -322,6 +322,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef VA_CHUNK
 #define VA_CHUNK 1
 #endif
+#ifndef VA_CHUNK_MB
+#define VA_CHUNK_MB 150.0
+#endif
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f32
 // a - b as one v_sub_f32 the vectoriser cannot re-pack (see the x differences in k_iter_tile)
@@ -747,14 +750,14 @@ void launch_iter(const TilePick& tp, const IterArgs& a, int npairs, hipStream_t 
 }
 
 // Pairs per chunk of a level: the iteration launches of a chunk re-read what the previous launch wrote, so a chunk
-// whose state (64 B per pixel) stays within ~110 MB is served largely by the Infinity Cache (measured on the 179^2
+// whose state (64 B per pixel) stays within ~150 MB (70, 110, 200 MB measured slower) is served largely by the Infinity Cache (measured on the 179^2
 // and 143^2 levels of the benchmark: -4 % each).  No chunking where a chunk could not fill the GPU.
 int chunk_pairs(int lw, int lh, const TilePick& tp, int NP)
 {
     const int tiles = tp.ntx * tp.nty;
     const bool w8 = kCfgs[tp.cfg].NW == 8;
     const int cp_min = (int)std::ceil((w8 ? 2.0 * 256 : 1.25 * 512) / tiles);
-    const int cp_mem = (int)(110.0e6 / ((double)lw * lh * 64.0));
+    const int cp_mem = (int)(VA_CHUNK_MB * 1.0e6 / ((double)lw * lh * 64.0));
     if (cp_mem < cp_min || cp_mem >= NP) return NP;
     const int n = va_cdiv(NP, cp_mem);
     return va_cdiv(NP, n);
