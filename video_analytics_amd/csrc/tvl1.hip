@@ -660,7 +660,7 @@ struct TilePick {
 // The 4-wave candidates (half-size tiles) run two workgroups per CU: one's load/store phase hides
 // behind the other's arithmetic (a few us exposed per 4096-pixel tile instead of ~15 us per 8192) and
 // the 4-wave barriers cost less (1.2 us per iteration instead of ~2.7 / 2).  The constants are fitted to the
-// per-level optimum found by brute force with the cache-aware workgroup order in place (tools/sweep in profiles/README.md).
+// per-level optimum found by brute force with the cache-aware workgroup order in place (tools/sweep_tvl1_tiles.py).
 double tile_launch_us(int cfg) { return kCfgs[cfg].NW == 8 ? 17.0 : 4.5; }
 double tile_iter_us(int cfg)
 {
