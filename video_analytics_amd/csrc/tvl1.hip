@@ -43,7 +43,13 @@ struct Taps {
 __device__ __forceinline__ int d_min(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int d_max(int a, int b) { return a > b ? a : b; }
 
-// S3
+// State / per-warp-constant planes store every aligned run of four pixels as [x0, x0+2, x0+1, x0+3]: a thread of
+// k_iter_tile then gets its four pixels as the register pairs E = (x0, x0+2), O = (x0+1, x0+3) straight from one
+// 16-byte load, and two of its four x differences per row are a single packed subtract (O - E).
+__device__ __forceinline__ int pslot(int x) { return (x & ~3) | ((x & 1) << 1) | ((x >> 1) & 1); }
+
+// S3 (PERM: the image uses the interleaved state layout above)
+template <bool PERM = false>
 __device__ __forceinline__ float bilinear(const float* __restrict__ img, int w, int h, int pitch, float x, float y)
 {
     x = fminf(fmaxf(x, 0.0f), (float)(w - 1));
@@ -51,8 +57,9 @@ __device__ __forceinline__ float bilinear(const float* __restrict__ img, int w, 
     const int x0 = (int)x, y0 = (int)y;
     const int x1 = d_min(x0 + 1, w - 1), y1 = d_min(y0 + 1, h - 1);
     const float ax = x - (float)x0, ay = y - (float)y0;
-    const float a = img[y0 * pitch + x0], b = img[y0 * pitch + x1];
-    const float c = img[y1 * pitch + x0], d = img[y1 * pitch + x1];
+    const int s0 = PERM ? pslot(x0) : x0, s1 = PERM ? pslot(x1) : x1;
+    const float a = img[y0 * pitch + s0], b = img[y0 * pitch + s1];
+    const float c = img[y1 * pitch + s0], d = img[y1 * pitch + s1];
     const float top = fmaf(ax, b - a, a);
     const float bot = fmaf(ax, d - c, c);
     return fmaf(ay, bot - top, top);
@@ -194,17 +201,17 @@ __global__ void k_warp(const float* __restrict__ pyr, size_t plane, int w, int h
     const float* I0 = pyr + (size_t)f0 * 3 * plane;
     const float* I1 = pyr + (size_t)(f0 + 1) * 3 * plane;
     const float* st = (which ? stB : stA) + (size_t)pair * kNF_STATE * plane;
-    const size_t o = (size_t)y * pitch + x;
-    const float u1 = active ? st[o] : 0.0f, u2 = active ? st[plane + o] : 0.0f;
+    const size_t o = (size_t)y * pitch + x, op = (size_t)y * pitch + pslot(x);
+    const float u1 = active ? st[op] : 0.0f, u2 = active ? st[plane + op] : 0.0f;
     float Iw, Iwx, Iwy;
     bilinear3_shfl(I1, plane, w, h, pitch, (float)x + u1, (float)y + u2, active, Iw, Iwx, Iwy);
     if (!active) return;
     const float grad = fmaf(Iwy, Iwy, Iwx * Iwx);
     float* r = ro + (size_t)pair * kNF_RO * plane;
-    r[o] = Iwx;
-    r[plane + o] = Iwy;
-    r[2 * plane + o] = fmaf(-Iwy, u2, fmaf(-Iwx, u1, Iw - I0[o]));
-    r[3 * plane + o] = grad < 1e-10f ? 0.0f : 1.0f / grad;
+    r[op] = Iwx;
+    r[plane + op] = Iwy;
+    r[2 * plane + op] = fmaf(-Iwy, u2, fmaf(-Iwx, u1, Iw - I0[o]));
+    r[3 * plane + op] = grad < 1e-10f ? 0.0f : 1.0f / grad;
 }
 
 // S8.  Upsample the coarse flow (cw,ch) of buffer `which` into tmp [pair][2][fplane].  A separate
@@ -223,8 +230,8 @@ __global__ void k_upsample(const float* __restrict__ stA, const float* __restric
     const int y = idx / fw, x = idx - y * fw;
     const float rx = (float)cw / (float)fw, ry = (float)ch / (float)fh;
     const size_t o = (size_t)y * fpitch + x;
-    dst[o] = bilinear(src, cw, ch, cpitch, (float)x * rx, (float)y * ry) * inv_step;
-    dst[fplane + o] = bilinear(src + cplane, cw, ch, cpitch, (float)x * rx, (float)y * ry) * inv_step;
+    dst[o] = bilinear<true>(src, cw, ch, cpitch, (float)x * rx, (float)y * ry) * inv_step;
+    dst[fplane + o] = bilinear<true>(src + cplane, cw, ch, cpitch, (float)x * rx, (float)y * ry) * inv_step;
 }
 
 // S4: start of a level: u from tmp, p = 0, everything in ping-pong buffer 0.
@@ -238,15 +245,15 @@ __global__ void k_level_init(const float* __restrict__ tmp, float* __restrict__ 
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= pitch * h) return;
     const int y = idx / pitch, x = idx - y * pitch;
-    const size_t o = (size_t)y * pitch + x;
+    const size_t o = (size_t)y * pitch + x, op = (size_t)y * pitch + pslot(x);  // (pitch is a multiple of 4: pslot stays inside the row)
     const float* t = tmp + (size_t)pair * 2 * plane;
     float* dst = st0 + (size_t)pair * kNF_STATE * plane;
-    dst[o] = x < w ? t[o] : 0.0f;
-    dst[plane + o] = x < w ? t[plane + o] : 0.0f;
-    dst[2 * plane + o] = 0.0f;
-    dst[3 * plane + o] = 0.0f;
-    dst[4 * plane + o] = 0.0f;
-    dst[5 * plane + o] = 0.0f;
+    dst[op] = x < w ? t[o] : 0.0f;
+    dst[plane + op] = x < w ? t[plane + o] : 0.0f;
+    dst[2 * plane + op] = 0.0f;
+    dst[3 * plane + op] = 0.0f;
+    dst[4 * plane + op] = 0.0f;
+    dst[5 * plane + op] = 0.0f;
 }
 
 // Zero the pitch padding of the nf planes of every pair (the per-warp constants: k_warp writes x < w only).
@@ -256,7 +263,7 @@ __global__ void k_zero_pad(float* __restrict__ buf, int nf, int w, int h, int pi
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= pw * h * nf) return;
     const int f = idx / (pw * h), r = idx - f * pw * h, y = r / pw, x = w + r - y * pw;
-    buf[((size_t)pair * nf + f) * plane + (size_t)y * pitch + x] = 0.0f;
+    buf[((size_t)pair * nf + f) * plane + (size_t)y * pitch + pslot(x)] = 0.0f;
 }
 
 __global__ void k_flow_out(const float* __restrict__ stA, const float* __restrict__ stB, const int* __restrict__ sel,
@@ -268,8 +275,8 @@ __global__ void k_flow_out(const float* __restrict__ stA, const float* __restric
     const int which = sel ? sel[pair] : cur;
     const float* st = (which ? stB : stA) + (size_t)pair * kNF_STATE * plane;
     const int y = idx / w, x = idx - y * w;
-    flow[((size_t)pair * 2) * w * h + idx] = st[(size_t)y * pitch + x];
-    flow[((size_t)pair * 2 + 1) * w * h + idx] = st[plane + (size_t)y * pitch + x];
+    flow[((size_t)pair * 2) * w * h + idx] = st[(size_t)y * pitch + pslot(x)];
+    flow[((size_t)pair * 2 + 1) * w * h + idx] = st[plane + (size_t)y * pitch + pslot(x)];
 }
 
 // S9
@@ -410,6 +417,7 @@ template <int RP, int C, int NW, int LX, bool EPS, bool FAST>
 __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
 {
     constexpr int R = 2 * RP, TW = LX * R, GPW = 64 / LX, NG = NW * GPW, TH = NG * C;
+    static_assert(RP == 2, "the interleaved pixel layout (pslot) is written for four pixels per thread row");
     // row NG of the exchange arrays is a dummy for idle lanes (64 % LX != 0); row NG + 1 stays zero: it is
     // the "row above" of the first and the "row below" of the last row group
     __shared__ __attribute__((aligned(16))) float sP12[NG + 2][TW], sP22[NG + 2][TW], sU1[NG + 2][TW], sU2[NG + 2][TW];
@@ -472,7 +480,7 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
     f2 mx[RP];
     float my[C];
 #pragma clang loop unroll(full)
-    for (int j = 0; j < RP; ++j) mx[j] = f2{x0 + 2 * j < w - 1 ? 1.0f : 0.0f, x0 + 2 * j + 1 < w - 1 ? 1.0f : 0.0f};
+    for (int j = 0; j < RP; ++j) mx[j] = f2{x0 + j < w - 1 ? 1.0f : 0.0f, x0 + j + 2 < w - 1 ? 1.0f : 0.0f};  // pack j = pixels x0+j, x0+j+2
 #pragma clang loop unroll(full)
     for (int c = 0; c < C; ++c) my[c] = y0 + c < h - 1 ? 1.0f : 0.0f;
 
@@ -523,10 +531,10 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
             }
 #pragma clang loop unroll(full)
             for (int j = 0; j < RP; ++j) {
-                // x differences as plain v_sub_f32 (2 cycles each; a packed subtract would need a
-                // v_pk_mov shuffle first), y differences packed
-                const f2 dx11 = f2{sub_s(p11[c][j].x, j > 0 ? p11[c][j > 0 ? j - 1 : 0].y : l11), sub_s(p11[c][j].y, p11[c][j].x)};
-                const f2 dx21 = f2{sub_s(p21[c][j].x, j > 0 ? p21[c][j > 0 ? j - 1 : 0].y : l21), sub_s(p21[c][j].y, p21[c][j].x)};
+                // backward x differences in the interleaved layout (pack 0 = E = pixels x0, x0+2; pack 1 = O = x0+1,
+                // x0+3): O - E is one packed subtract; E needs the left lane's last pixel and O.x: two v_sub_f32
+                const f2 dx11 = j == 0 ? f2{sub_s(p11[c][0].x, l11), sub_s(p11[c][0].y, p11[c][1].x)} : p11[c][1] - p11[c][0];
+                const f2 dx21 = j == 0 ? f2{sub_s(p21[c][0].x, l21), sub_s(p21[c][0].y, p21[c][1].x)} : p21[c][1] - p21[c][0];
                 const f2 a12 = c > 0 ? p12[c > 0 ? c - 1 : 0][j] : A12[j];
                 const f2 a22 = c > 0 ? p22[c > 0 ? c - 1 : 0][j] : A22[j];
                 const f2 div1 = dx11 + (p12[c][j] - a12);
@@ -539,12 +547,12 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
                 const f2 n1 = pk_fma(theta, div1, v1);
                 const f2 n2 = pk_fma(theta, div2, v2);
                 if constexpr (EPS) {
-                    const int y = y0 + c, x = x0 + 2 * j;
+                    const int y = y0 + c, x = x0 + j;  // pack j holds pixels x and x + 2
                     const f2 e1 = n1 - u1[c][j], e2 = n2 - u2[c][j];
                     const f2 e = pk_fma(e2, e2, e1 * e1);
                     if (y >= vy0 && y < vy1) {
                         if (x >= vx0 && x < vx1) qsum += (unsigned long long)(fminf(e.x, 1024.0f) * 4294967296.0f);
-                        if (x + 1 >= vx0 && x + 1 < vx1) qsum += (unsigned long long)(fminf(e.y, 1024.0f) * 4294967296.0f);
+                        if (x + 2 >= vx0 && x + 2 < vx1) qsum += (unsigned long long)(fminf(e.y, 1024.0f) * 4294967296.0f);
                     }
                 }
                 u1[c][j] = n1;
@@ -575,8 +583,9 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
             const float r1 = dpp_from_right(u1[c][0].x), r2 = dpp_from_right(u2[c][0].x);
 #pragma clang loop unroll(full)
             for (int j = 0; j < RP; ++j) {
-                const f2 d1x = f2{sub_s(u1[c][j].y, u1[c][j].x), sub_s(j < RP - 1 ? u1[c][j < RP - 1 ? j + 1 : 0].x : r1, u1[c][j].y)};
-                const f2 d2x = f2{sub_s(u2[c][j].y, u2[c][j].x), sub_s(j < RP - 1 ? u2[c][j < RP - 1 ? j + 1 : 0].x : r2, u2[c][j].y)};
+                // forward x differences: E's are O - E (packed); O's need E.y and the right lane's first pixel
+                const f2 d1x = j == 0 ? u1[c][1] - u1[c][0] : f2{sub_s(u1[c][0].y, u1[c][1].x), sub_s(r1, u1[c][1].y)};
+                const f2 d2x = j == 0 ? u2[c][1] - u2[c][0] : f2{sub_s(u2[c][0].y, u2[c][1].x), sub_s(r2, u2[c][1].y)};
                 const f2 b1 = c < C - 1 ? u1[c < C - 1 ? c + 1 : 0][j] : B1[j];
                 const f2 b2 = c < C - 1 ? u2[c < C - 1 ? c + 1 : 0][j] : B2[j];
                 const f2 u1x = d1x * mx[j], u1y = (b1 - u1[c][j]) * my[c];
