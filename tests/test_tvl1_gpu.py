@@ -197,3 +197,11 @@ def test_bad_arguments_raise_value_error():
         vflow.tvl1_flow(torch.zeros(1, 2, 64, 64, dtype=torch.uint8, device="cuda"), scale_step=1.5)
     with pytest.raises(ValueError):
         vflow.tvl1_flow(torch.zeros(1, 2, 64, 64, dtype=torch.uint8))  # host tensor
+    fr = torch.zeros(1, 3, 64, 64, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError):
+        vflow.tvl1_flow(fr, out=torch.empty(1, 2, 64, 64, device="cuda"))  # out for 2 pairs must be [2,2,64,64]
+    with pytest.raises(ValueError):
+        vflow.tvl1_flow(fr, tile_mask=1 << 9)  # only 8 tile candidates
+    out = torch.empty(2, 2, 64, 64, device="cuda")
+    got = vflow.tvl1_flow(fr, out=out)
+    assert got.data_ptr() == out.data_ptr() and bool((got == 0).all())  # identical frames: zero flow, written in place
