@@ -132,7 +132,10 @@ typedef struct va_tvl1_params {
     int tile_mask;    /* tuning/testing: bit i allows register-tile candidate i of the inner-iteration
                          kernel (bits 0-3: 256x32, 128x64, 84x96, 64x128 pixels, one 8-wave workgroup
                          per CU; bits 4-7: 256x16, 128x32, 84x48, 64x64, two 4-wave workgroups per
-                         CU).  0 (default) = all.  Results do not depend on it. */
+                         CU).  Bit 8 (256): iterate every level with the streaming kernel (a wave carries a
+                         128-column strip row by row through 10 iterations per pass) instead of the
+                         register tiles; fixed-iteration mode only.  0 (default) = library choice per
+                         level.  Results do not depend on it. */
 } va_tvl1_params;
 
 void va_tvl1_default_params(va_tvl1_params* p);
@@ -141,8 +144,9 @@ void va_tvl1_default_params(va_tvl1_params* p);
 int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* hs);
 
 /* The register tiling va_tvl1_flow will use, level by level (host logic; HOST array of >= 6*16 ints): per level
- * { tile width, tile height, waves per workgroup, block depth K, tiles in x, tiles in y }.  Returns the number
- * of levels (0 on bad arguments). */
+ * { tile width, tile height, waves per workgroup, block depth K, tiles in x, tiles in y }; a level that streams
+ * reports { 128, 0 (rows stream through), 1, 10, strips in x, 0 (chunks of rows: chosen per call from the
+ * number of pairs) }.  Returns the number of levels (0 on bad arguments). */
 int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out);
 
 size_t va_tvl1_workspace_bytes(int w, int h, int n_seq, int frames_per_seq, const va_tvl1_params* p);

@@ -64,6 +64,36 @@ def test_every_register_tile_candidate_bit_exact(oracle_tvl1, bit):
     assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("H,W,nch", [(48, 64, 0), (100, 64, 3), (64, 300, 1), (150, 300, 3), (224, 224, 0), (57, 131, 1), (301, 259, 4)])
+def test_streaming_kernel_bit_exact(oracle_tvl1, monkeypatch, H, W, nch):
+    # tile_mask bit 8 forces k_iter_stream (the time-skewed row pipeline) on every level: one strip / several strips
+    # with x halos, one chunk / several chunks of rows (VA_STREAM_NCH), iteration counts that are and are not a
+    # multiple of the pipeline depth (10), ragged widths with pitch padding
+    monkeypatch.setenv("VA_STREAM_NCH", str(nch))
+    gray = _frames(1, 3, H, W, seed=H + W)
+    for iters, warps, nscales in ((10, 1, 1), (23, 2, 3)):
+        ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=warps, nscales=nscales, tile_mask=1 << 8)
+        assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
+def test_streaming_kernel_fast_math_and_mixed_levels(oracle_tvl1, monkeypatch):
+    # levels that stream (plain row order) next to levels on the register tiles (interleaved pixel order): the
+    # up-sampling between them converts; VA_STREAM picks the levels
+    gray = _frames(2, 2, 224, 224, seed=77)
+    ref = oracle_tvl1.tvl1_flow(gray.numpy(), oracle_tvl1.default_params(epsilon=0.0, iters=25, warps=2, nscales=4), nthreads=8)
+    from video_analytics_amd import flow as vflow
+    for bits in ("0", "5", "10", "15"):
+        monkeypatch.setenv("VA_STREAM", bits)
+        out = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=25, warps=2, nscales=4).cpu().numpy()
+        assert np.array_equal(out, ref), "VA_STREAM=%s: max abs diff %g" % (bits, np.abs(out - ref).max())
+    monkeypatch.delenv("VA_STREAM")
+    exact = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=25, warps=2, nscales=4, tile_mask=1 << 8)
+    fast = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=25, warps=2, nscales=4, tile_mask=1 << 8, fast_math=1)
+    tiles = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=25, warps=2, nscales=4, tile_mask=0xFF, fast_math=1)
+    assert torch.equal(fast, tiles)  # the 1-ulp variant is the same arithmetic in both kernels
+    assert (fast - exact).abs().max().item() < 1e-3
+
+
 @pytest.mark.parametrize("fill", [0xFF, 0x7F])
 def test_result_does_not_depend_on_what_the_workspace_held(oracle_tvl1, fill):
     # the caller owns the workspace and may hand over anything: NaN (0xFFFFFFFF) and huge (0x7F7F7F7F)
@@ -201,7 +231,7 @@ def test_bad_arguments_raise_value_error():
     with pytest.raises(ValueError):
         vflow.tvl1_flow(fr, out=torch.empty(1, 2, 64, 64, device="cuda"))  # out for 2 pairs must be [2,2,64,64]
     with pytest.raises(ValueError):
-        vflow.tvl1_flow(fr, tile_mask=1 << 9)  # only 8 tile candidates
+        vflow.tvl1_flow(fr, tile_mask=1 << 9)  # 8 tile candidates + the streaming bit
     out = torch.empty(2, 2, 64, 64, device="cuda")
     got = vflow.tvl1_flow(fr, out=out)
     assert got.data_ptr() == out.data_ptr() and bool((got == 0).all())  # identical frames: zero flow, written in place

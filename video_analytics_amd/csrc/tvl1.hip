@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <utility>
+#include <type_traits>
 
 namespace {
 
@@ -46,18 +47,18 @@ __device__ __forceinline__ int d_max(int a, int b) { return a > b ? a : b; }
 // State / per-warp-constant planes store every aligned run of four pixels as [x0, x0+2, x0+1, x0+3]: a thread of
 // k_iter_tile then gets its four pixels as the register pairs E = (x0, x0+2), O = (x0+1, x0+3) straight from one
 // 16-byte load, and two of its four x differences per row are a single packed subtract (O - E).
-__device__ __forceinline__ int pslot(int x) { return (x & ~3) | ((x & 1) << 1) | ((x >> 1) & 1); }
+// (`perm` = 0: plain row order, the layout of the levels that k_iter_stream iterates.)
+__device__ __forceinline__ int pslot(int x, int perm) { return perm ? ((x & ~3) | ((x & 1) << 1) | ((x >> 1) & 1)) : x; }
 
-// S3 (PERM: the image uses the interleaved state layout above)
-template <bool PERM = false>
-__device__ __forceinline__ float bilinear(const float* __restrict__ img, int w, int h, int pitch, float x, float y)
+// S3 (perm: the image uses the interleaved state layout above)
+__device__ __forceinline__ float bilinear(const float* __restrict__ img, int w, int h, int pitch, float x, float y, int perm = 0)
 {
     x = fminf(fmaxf(x, 0.0f), (float)(w - 1));
     y = fminf(fmaxf(y, 0.0f), (float)(h - 1));
     const int x0 = (int)x, y0 = (int)y;
     const int x1 = d_min(x0 + 1, w - 1), y1 = d_min(y0 + 1, h - 1);
     const float ax = x - (float)x0, ay = y - (float)y0;
-    const int s0 = PERM ? pslot(x0) : x0, s1 = PERM ? pslot(x1) : x1;
+    const int s0 = pslot(x0, perm), s1 = pslot(x1, perm);
     const float a = img[y0 * pitch + s0], b = img[y0 * pitch + s1];
     const float c = img[y1 * pitch + s0], d = img[y1 * pitch + s1];
     const float top = fmaf(ax, b - a, a);
@@ -182,7 +183,7 @@ __device__ __forceinline__ void bilinear3_shfl(const float* __restrict__ I1, siz
 // lower-order).
 __global__ void k_warp(const float* __restrict__ pyr, size_t plane, int w, int h, int pitch, int fps,
                        const float* __restrict__ stA, const float* __restrict__ stB, const int* __restrict__ sel, int cur,
-                       int* __restrict__ base, float* __restrict__ ro, int pair0)
+                       int* __restrict__ base, float* __restrict__ ro, int pair0, int perm)
 {
     // XCD-aware workgroup order (as in k_iter_tile): the pixel blocks of a pair gather from one L2
     unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
@@ -201,7 +202,7 @@ __global__ void k_warp(const float* __restrict__ pyr, size_t plane, int w, int h
     const float* I0 = pyr + (size_t)f0 * 3 * plane;
     const float* I1 = pyr + (size_t)(f0 + 1) * 3 * plane;
     const float* st = (which ? stB : stA) + (size_t)pair * kNF_STATE * plane;
-    const size_t o = (size_t)y * pitch + x, op = (size_t)y * pitch + pslot(x);
+    const size_t o = (size_t)y * pitch + x, op = (size_t)y * pitch + pslot(x, perm);
     const float u1 = active ? st[op] : 0.0f, u2 = active ? st[plane + op] : 0.0f;
     float Iw, Iwx, Iwy;
     bilinear3_shfl(I1, plane, w, h, pitch, (float)x + u1, (float)y + u2, active, Iw, Iwx, Iwy);
@@ -219,7 +220,7 @@ __global__ void k_warp(const float* __restrict__ pyr, size_t plane, int w, int h
 // different ping-pong buffers, and the coarse and fine layouts of different pairs overlap.
 __global__ void k_upsample(const float* __restrict__ stA, const float* __restrict__ stB, const int* __restrict__ sel,
                            int cur, int cw, int ch, int cpitch, size_t cplane, float* __restrict__ tmp, int fw, int fh,
-                           int fpitch, size_t fplane, float inv_step)
+                           int fpitch, size_t fplane, float inv_step, int cperm)
 {
     const int pair = blockIdx.y;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -230,8 +231,8 @@ __global__ void k_upsample(const float* __restrict__ stA, const float* __restric
     const int y = idx / fw, x = idx - y * fw;
     const float rx = (float)cw / (float)fw, ry = (float)ch / (float)fh;
     const size_t o = (size_t)y * fpitch + x;
-    dst[o] = bilinear<true>(src, cw, ch, cpitch, (float)x * rx, (float)y * ry) * inv_step;
-    dst[fplane + o] = bilinear<true>(src + cplane, cw, ch, cpitch, (float)x * rx, (float)y * ry) * inv_step;
+    dst[o] = bilinear(src, cw, ch, cpitch, (float)x * rx, (float)y * ry, cperm) * inv_step;
+    dst[fplane + o] = bilinear(src + cplane, cw, ch, cpitch, (float)x * rx, (float)y * ry, cperm) * inv_step;
 }
 
 // S4: start of a level: u from tmp, p = 0, everything in ping-pong buffer 0.
@@ -239,13 +240,13 @@ __global__ void k_upsample(const float* __restrict__ stA, const float* __restric
 // runs, and although no padding value can reach a valid pixel (the forward differences at x = w-1
 // are multiplied by 0), a NaN/Inf bit pattern left there by an earlier owner of the workspace would
 // (NaN * 0 = NaN).  Everything the kernels themselves write is finite.
-__global__ void k_level_init(const float* __restrict__ tmp, float* __restrict__ st0, int w, int h, int pitch, size_t plane)
+__global__ void k_level_init(const float* __restrict__ tmp, float* __restrict__ st0, int w, int h, int pitch, size_t plane, int perm)
 {
     const int pair = blockIdx.y;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= pitch * h) return;
     const int y = idx / pitch, x = idx - y * pitch;
-    const size_t o = (size_t)y * pitch + x, op = (size_t)y * pitch + pslot(x);  // (pitch is a multiple of 4: pslot stays inside the row)
+    const size_t o = (size_t)y * pitch + x, op = (size_t)y * pitch + pslot(x, perm);  // (pitch is a multiple of 4: pslot stays inside the row)
     const float* t = tmp + (size_t)pair * 2 * plane;
     float* dst = st0 + (size_t)pair * kNF_STATE * plane;
     dst[op] = x < w ? t[o] : 0.0f;
@@ -257,17 +258,17 @@ __global__ void k_level_init(const float* __restrict__ tmp, float* __restrict__ 
 }
 
 // Zero the pitch padding of the nf planes of every pair (the per-warp constants: k_warp writes x < w only).
-__global__ void k_zero_pad(float* __restrict__ buf, int nf, int w, int h, int pitch, size_t plane)
+__global__ void k_zero_pad(float* __restrict__ buf, int nf, int w, int h, int pitch, size_t plane, int perm)
 {
     const int pair = blockIdx.y, pw = pitch - w;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= pw * h * nf) return;
     const int f = idx / (pw * h), r = idx - f * pw * h, y = r / pw, x = w + r - y * pw;
-    buf[((size_t)pair * nf + f) * plane + (size_t)y * pitch + pslot(x)] = 0.0f;
+    buf[((size_t)pair * nf + f) * plane + (size_t)y * pitch + pslot(x, perm)] = 0.0f;
 }
 
 __global__ void k_flow_out(const float* __restrict__ stA, const float* __restrict__ stB, const int* __restrict__ sel,
-                           int cur, int w, int h, int pitch, size_t plane, float* __restrict__ flow)
+                           int cur, int w, int h, int pitch, size_t plane, float* __restrict__ flow, int perm)
 {
     const int pair = blockIdx.y;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -275,8 +276,8 @@ __global__ void k_flow_out(const float* __restrict__ stA, const float* __restric
     const int which = sel ? sel[pair] : cur;
     const float* st = (which ? stB : stA) + (size_t)pair * kNF_STATE * plane;
     const int y = idx / w, x = idx - y * w;
-    flow[((size_t)pair * 2) * w * h + idx] = st[(size_t)y * pitch + pslot(x)];
-    flow[((size_t)pair * 2 + 1) * w * h + idx] = st[plane + (size_t)y * pitch + pslot(x)];
+    flow[((size_t)pair * 2) * w * h + idx] = st[(size_t)y * pitch + pslot(x, perm)];
+    flow[((size_t)pair * 2 + 1) * w * h + idx] = st[plane + (size_t)y * pitch + pslot(x, perm)];
 }
 
 // S9
@@ -648,6 +649,226 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
     }
 }
 
+// ---------------------------------------------------------------- streaming inner iterations ---
+//
+// k_iter_stream: the same S6 arithmetic organised as a time-skewed pipeline along y ("3.5-D blocking").  One WAVE owns a
+// strip of 128 columns (2 pixels per lane, plain row order) and a chunk of rows [a0, b0); it streams the rows of the
+// strip top to bottom ONCE per launch and carries every row through K iterations on the way: level t (t = 0 .. K-1)
+// turns the time-t values of its incoming row into time-(t+1) values one row behind, so level t works on row
+// (s - t) at step s.  A level keeps only ONE row of p (its row above) and one row of the new u (waiting for its row
+// below) in registers: 12 VGPRs per level, 120 for K = 10.  The per-warp constants of the K rows in flight sit in a
+// private LDS ring (each lane reads back only what it wrote: no barrier anywhere in the kernel).
+// Against k_iter_tile's overlapped tiles (halo K on four sides: 2.0x redundant work on the 224^2 level) a strip pays
+// the halo only in x where the level is wider than 128 columns and a triangular K(K+1) level-rows per chunk in y.
+struct StreamArgs {
+    const float* ro;
+    const float* sin;
+    float* sout;
+    size_t plane;
+    int w, h, pitch;
+    int nsx, nch, R, HX;  // strips per row, chunks per column, rows per chunk, x halo of interior strip edges
+    int K;                // iterations in this launch (<= KS)
+    int pair0, rev;
+    float l_t, taut, theta;
+};
+
+template <int KS, bool FAST>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_iter_stream(StreamArgs a)
+{
+    constexpr int NR = KS - 1;  // ring rows: level t >= 1 reads row s - t; row s is written at the end of step s
+    __shared__ f2 ring[NR][kNF_RO][64];
+
+    unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const unsigned nb = gridDim.x * gridDim.y, q = nb / 8, r = nb % 8, xcd = lid % 8, kk = lid / 8;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+        if (a.rev) lid = nb - 1 - lid;
+    }
+    const int pair = a.pair0 + (int)(lid / gridDim.x), job = (int)(lid % gridDim.x);
+    const int sx = job % a.nsx, ch = job / a.nsx;
+    const int w = a.w, h = a.h, pitch = a.pitch, K = a.K;
+    const int lane = threadIdx.x;
+    const int ox = sx * (128 - 2 * a.HX);
+    const int vx0 = ox + (sx > 0 ? a.HX : 0), vx1 = (sx == a.nsx - 1) ? pitch : ox + 128 - a.HX;
+    const int x0 = ox + 2 * lane;
+    const bool colok = x0 < pitch;
+    const bool stok = colok && x0 >= vx0 && x0 < vx1;
+    const int a0 = ch * a.R, b0 = d_min(h, a0 + a.R);
+    const int ys = d_max(0, a0 - K), ye = d_min(h, b0 + K);
+
+    // buffer addressing: resource (scalar) + per-lane byte offset (one VGPR) + scalar plane/row offset.  Lanes beyond the
+    // pitch read column 0 (finite values that no valid pixel can see: their differences are multiplied by mx = 0) and
+    // never store.
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    const int planeb = (int)(a.plane * sizeof(float)), pitchb = pitch * (int)sizeof(float);
+    const __amdgpu_buffer_rsrc_t rs_ro = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.ro + (size_t)pair * kNF_RO * a.plane), 0, kNF_RO * planeb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.sin + (size_t)pair * kNF_STATE * a.plane), 0, kNF_STATE * planeb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.sout + (size_t)pair * kNF_STATE * a.plane, 0,
+                                                                           kNF_STATE * planeb, 0x00020000);
+    const int loff = colok ? x0 * (int)sizeof(float) : 0;
+
+    const f2 mx = f2{x0 < w - 1 ? 1.0f : 0.0f, x0 + 1 < w - 1 ? 1.0f : 0.0f};
+    const float l_t = a.l_t;
+    const f2 taut = splat(a.taut), theta = splat(a.theta), one = splat(1.0f), zero = splat(0.0f);
+
+#pragma clang loop unroll(full)
+    for (int r = 0; r < NR; ++r)
+#pragma clang loop unroll(full)
+        for (int f = 0; f < kNF_RO; ++f) ring[r][f][lane] = zero;
+
+    f2 P11[KS], P12[KS], P21[KS], P22[KS], U1[KS], U2[KS];
+#pragma clang loop unroll(full)
+    for (int t = 0; t < KS; ++t) P11[t] = P12[t] = P21[t] = P22[t] = U1[t] = U2[t] = zero;
+
+    auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int f, int y) -> f2 {
+        return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, loff, f * planeb + y * pitchb, 0));
+    };
+    auto st = [&](f2 v, int f, int y) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), rs_out, loff, f * planeb + y * pitchb, 0); };
+    f2 nst[kNF_STATE], nro[kNF_RO];
+    {
+        const int y = ys < ye ? ys : 0;  // (an empty chunk cannot occur: b0 > a0)
+#pragma clang loop unroll(full)
+        for (int f = 0; f < kNF_STATE; ++f) nst[f] = ld(rs_in, f, y);
+#pragma clang loop unroll(full)
+        for (int f = 0; f < kNF_RO; ++f) nro[f] = ld(rs_ro, f, y);
+    }
+
+    const int nsteps = b0 - ys + K;  // level K-1 emits row b0-1 when row b0 (or the dummy row h) comes in
+    auto step = [&](const int s, auto steady_tag) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        f2 c_u1 = nst[0], c_u2 = nst[1], c_p11 = nst[2], c_p12 = nst[3], c_p21 = nst[4], c_p22 = nst[5];
+        const f2 r0[kNF_RO] = {nro[0], nro[1], nro[2], nro[3]};
+        {
+            // next row (beyond the last row of the strip: row ye - 1 again -- finite values nobody uses, or, at the image
+            // bottom, the dummy row h whose only consumer multiplies its difference by my = 0)
+            const int rn = d_min(ys + s + 1, ye - 1);
+#pragma clang loop unroll(full)
+            for (int f = 0; f < kNF_STATE; ++f) nst[f] = ld(rs_in, f, rn);
+#pragma clang loop unroll(full)
+            for (int f = 0; f < kNF_RO; ++f) nro[f] = ld(rs_ro, f, rn);
+            __builtin_amdgcn_sched_barrier(0);  // the loads stay at the top of the step: a whole step hides their latency
+        }
+        // One level: phase A on the incoming row C (k_iter_tile's arithmetic, operation for operation), phase B on the
+        // row above it (whose lower neighbour is the row just computed); the level keeps the incoming p and the new u,
+        // and passes on (its old u, the new p) = the time-(t+1) values of the row above.
+        auto level = [&](int t, const f2 wx, const f2 wy, const f2 rc, const f2 ig, const f2 my) __attribute__((always_inline)) {
+            const float l11 = dpp_from_left(c_p11.y), l21 = dpp_from_left(c_p21.y);
+            const f2 dx11 = f2{sub_s(c_p11.x, l11), sub_s(c_p11.y, c_p11.x)};
+            const f2 dx21 = f2{sub_s(c_p21.x, l21), sub_s(c_p21.y, c_p21.x)};
+            const f2 div1 = dx11 + (c_p12 - P12[t]);
+            const f2 div2 = dx21 + (c_p22 - P22[t]);
+            const f2 rho = pk_fma(wy, c_u2, pk_fma(wx, c_u1, rc));
+            const f2 tt = -rho * ig;
+            const f2 fi = f2{__builtin_amdgcn_fmed3f(tt.x, -l_t, l_t), __builtin_amdgcn_fmed3f(tt.y, -l_t, l_t)};
+            const f2 v1 = pk_fma(fi, wx, c_u1);
+            const f2 v2 = pk_fma(fi, wy, c_u2);
+            const f2 n1 = pk_fma(theta, div1, v1);
+            const f2 n2 = pk_fma(theta, div2, v2);
+            const float r1 = dpp_from_right(U1[t].x), r2 = dpp_from_right(U2[t].x);
+            const f2 d1x = f2{sub_s(U1[t].y, U1[t].x), sub_s(r1, U1[t].y)};
+            const f2 d2x = f2{sub_s(U2[t].y, U2[t].x), sub_s(r2, U2[t].y)};
+            const f2 u1x = d1x * mx, u1y = (n1 - U1[t]) * my;
+            const f2 u2x = d2x * mx, u2y = (n2 - U2[t]) * my;
+            const f2 s1 = pk_fma(u1y, u1y, pk_fma(u1x, u1x, splat(kSqrtReg)));
+            const f2 s2 = pk_fma(u2y, u2y, pk_fma(u2x, u2x, splat(kSqrtReg)));
+            f2 q1, q2;
+            if constexpr (FAST) {
+                const f2 g1 = f2{__builtin_amdgcn_sqrtf(s1.x), __builtin_amdgcn_sqrtf(s1.y)};
+                const f2 g2 = f2{__builtin_amdgcn_sqrtf(s2.x), __builtin_amdgcn_sqrtf(s2.y)};
+                const f2 d1 = pk_fma(taut, g1, one), d2 = pk_fma(taut, g2, one);
+                q1 = f2{__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)};
+                q2 = f2{__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)};
+            } else {
+                const f2 g1 = sqrt_exact_pk(s1), g2 = sqrt_exact_pk(s2);
+                const f2 d1 = pk_fma(taut, g1, one), d2 = pk_fma(taut, g2, one);
+                const f2 rinv = rcp_exact_pk(d1 * d2);
+                q1 = d2 * rinv;
+                q2 = d1 * rinv;
+            }
+            const f2 o11 = pk_fma(taut, u1x, P11[t]) * q1;
+            const f2 o12 = pk_fma(taut, u1y, P12[t]) * q1;
+            const f2 o21 = pk_fma(taut, u2x, P21[t]) * q2;
+            const f2 o22 = pk_fma(taut, u2y, P22[t]) * q2;
+            const f2 ou1 = U1[t], ou2 = U2[t];
+            P11[t] = c_p11;
+            P12[t] = c_p12;
+            P21[t] = c_p21;
+            P22[t] = c_p22;
+            U1[t] = n1;
+            U2[t] = n2;
+            c_u1 = ou1;
+            c_u2 = ou2;
+            c_p11 = o11;
+            c_p12 = o12;
+            c_p21 = o21;
+            c_p22 = o22;
+        };
+        bool emitted;
+        // levels in flight: tmin .. tmax (level t takes the rows [a0 - (K - t), b0 + (K - t)) of the image and, at
+        // the image bottom, the dummy row h; with rin = ys + s - t that is a contiguous range of t)
+        const int rs = ys + s, s0 = s % NR;  // row s of the strip lives in ring slot s % NR
+        const int tmin = d_max(0, rs - h), tmax = d_min(d_min(K - 1, rs), (rs - a0 + K) >> 1);
+        if constexpr (STEADY) {
+            // steady state: every level works, no row is the image's last: straight-line code
+            // the constants of level t + 1 are fetched from the ring while level t computes
+            f2 q[kNF_RO] = {r0[0], r0[1], r0[2], r0[3]};
+#pragma clang loop unroll(full)
+            for (int t = 0; t < KS; ++t) {
+                f2 nq[kNF_RO] = {zero, zero, zero, zero};
+                if (t + 1 < KS) {
+                    const int slot = s0 - (t + 1) < 0 ? s0 - (t + 1) + NR : s0 - (t + 1);
+#pragma clang loop unroll(full)
+                    for (int f = 0; f < kNF_RO; ++f) nq[f] = ring[slot][f][lane];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                level(t, q[0], q[1], q[2], q[3], one);
+#pragma clang loop unroll(full)
+                for (int f = 0; f < kNF_RO; ++f) q[f] = nq[f];
+            }
+            emitted = true;
+        } else {
+            emitted = false;
+#pragma clang loop unroll(full)
+            for (int t = 0; t < KS; ++t) {
+                const bool act = t >= tmin && t <= tmax;
+                if (t == K - 1) emitted = act;
+                if (act) {
+                    const int rin = rs - t;  // the row coming into level t
+                    const f2 my = splat(rin - 1 < h - 1 ? 1.0f : 0.0f);
+                    if (t == 0) {
+                        level(0, r0[0], r0[1], r0[2], r0[3], my);
+                    } else {
+                        const int slot = s0 - t < 0 ? s0 - t + NR : s0 - t;
+                        level(t, ring[slot][0][lane], ring[slot][1][lane], ring[slot][2][lane], ring[slot][3][lane], my);
+                    }
+                }
+            }
+        }
+        const int rout = ys + s - K;  // the row that left level K-1 in this step, K iterations on
+        if (emitted && stok && rout >= a0 && rout < b0) {
+            st(c_u1, 0, rout);
+            st(c_u2, 1, rout);
+            st(c_p11, 2, rout);
+            st(c_p12, 3, rout);
+            st(c_p21, 4, rout);
+            st(c_p22, 5, rout);
+        }
+        {
+#pragma clang loop unroll(full)
+            for (int f = 0; f < kNF_RO; ++f) ring[s0][f][lane] = r0[f];
+        }
+    };
+    // steady state (every level at work, no level at the image's last row): steps [s_a, s_b)
+    int s_a = d_max(KS - 1, a0 + KS - 2) - ys, s_b = d_min(nsteps, h - ys);
+    if (K != KS || s_a > s_b) s_a = s_b = 0;
+    int s = 0;
+    for (; s < s_a; ++s) step(s, std::false_type{});
+    for (; s < s_b; ++s) step(s, std::true_type{});
+    for (; s < nsteps; ++s) step(s, std::false_type{});
+}
+
 // ---------------------------------------------------------------- host side -------------------
 
 struct TileCfg {
@@ -758,6 +979,48 @@ void launch_iter(const TilePick& tp, const IterArgs& a, int npairs, hipStream_t 
     }
 }
 
+// ---- k_iter_stream: strips x chunks of a level
+constexpr int kStreamK = 10;        // pipeline depth the kernel is compiled for (300 = 30 x 10)
+constexpr int kStreamBit = 1 << 8;  // va_tvl1_params.tile_mask bit: iterate with k_iter_stream
+struct StreamPick {
+    int nsx, nch, R, HX;
+};
+int stream_env(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+StreamPick pick_stream(int w, int h, int npairs)
+{
+    StreamPick sp{};
+    sp.HX = kStreamK;  // even: strip origins stay 8-byte aligned
+    sp.nsx = tiles_1d(w, 128, sp.HX);
+    // chunks: about one job per two wave slots of the GPU (256 CUs x 8; measured best with one and with two concurrent
+    // calls on different HIP streams), rows per chunk not below 32
+    const int slots = stream_env("VA_STREAM_SLOTS", 1024);
+    int nch = stream_env("VA_STREAM_NCH", 0);
+    if (nch <= 0) nch = (int)((double)slots / ((double)npairs * sp.nsx) + 0.5);
+    if (nch > h / 32) nch = h / 32;
+    if (nch < 1) nch = 1;
+    sp.R = va_cdiv(h, nch);
+    sp.nch = va_cdiv(h, sp.R);
+    return sp;
+}
+// Level (w, h) of the pyramid iterates with k_iter_stream: wherever its 128-column strips are well filled and the level
+// is large enough for a GPU-full of strip x chunk jobs (measured, tools/bench_tvl1_levels.py: 224^2 and every level of
+// the 1280x720 pyramid win, 179^2 and below lose to the register tiles).  tile_mask bit 8 forces it (tests);
+// VA_STREAM=<bits> is an experiment switch (bit s = level s, 0 = never).
+bool level_streams(const va_tvl1_params* p, bool eps, int s, int w, int h, size_t plane)
+{
+    if (eps || (double)plane * kNF_STATE * sizeof(float) >= 2147483648.0) return false;  // 32-bit buffer offsets
+    if (p->tile_mask & kStreamBit) return true;
+    if (p->tile_mask != 0) return false;
+    const int env = stream_env("VA_STREAM", -1);
+    if (env >= 0) return ((env >> s) & 1) != 0;
+    const int nsx = tiles_1d(w, 128, kStreamK);
+    return (double)w >= 0.8 * 128.0 * nsx && (double)w * h >= 40000.0;
+}
+
 // Pairs per chunk of a level: the iteration launches of a chunk re-read what the previous launch wrote, so a chunk
 // whose state (64 B per pixel) stays within ~150 MB (70, 110, 200 MB measured slower) is served largely by the Infinity Cache (measured on the 179^2
 // and 143^2 levels of the benchmark: -4 % each).  No chunking where a chunk could not fill the GPU.
@@ -805,7 +1068,7 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
     VA_CHECK_ARG(p->tau > 0.0f && p->lambda > 0.0f && p->theta > 0.0f, "va_tvl1: tau, lambda, theta must be > 0");
     VA_CHECK_ARG(p->block_iters >= 0 && p->block_iters <= 64, "va_tvl1: block_iters must be in [0,64]");
     VA_CHECK_ARG(p->fast_math == 0 || p->fast_math == 1, "va_tvl1: fast_math must be 0 or 1");
-    VA_CHECK_ARG(p->tile_mask >= 0 && p->tile_mask < (1 << kNumCfgs), "va_tvl1: tile_mask must be in [0, %d]", (1 << kNumCfgs) - 1);
+    VA_CHECK_ARG(p->tile_mask >= 0 && p->tile_mask < (1 << (kNumCfgs + 1)), "va_tvl1: tile_mask must be in [0, %d]", (1 << (kNumCfgs + 1)) - 1);
     VA_CHECK_ARG(p->tau / p->theta <= 1000.0f && p->lambda * p->theta <= 1000.0f, "va_tvl1: tau/theta and lambda*theta must be <= 1000");
     return VA_OK;
 }
@@ -902,8 +1165,15 @@ extern "C" int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out
     int K0 = p->block_iters;
     if (p->epsilon > 0.0f) K0 = 1;
     for (int s = 0; s < ns; ++s) {
-        const TilePick tp = K0 > 0 ? pick_tiles(ws[s], hs[s], K0, (unsigned)p->tile_mask) : pick_tiles_auto(ws[s], hs[s], p->iters, (unsigned)p->tile_mask);
+        const unsigned tmask = (unsigned)p->tile_mask & (unsigned)(kStreamBit - 1);
+        const TilePick tp = K0 > 0 ? pick_tiles(ws[s], hs[s], K0, tmask) : pick_tiles_auto(ws[s], hs[s], p->iters, tmask);
         const TileCfg& c = kCfgs[tp.cfg];
+        const int lp = (ws[s] + 3) / 4 * 4;
+        if (level_streams(p, p->epsilon > 0.0f, s, ws[s], hs[s], va_align_up((size_t)lp * hs[s], 64))) {
+            const int plan[6] = {128, 0, 1, kStreamK, tiles_1d(ws[s], 128, kStreamK), 0};
+            memcpy(out + 6 * s, plan, sizeof(plan));
+            continue;
+        }
         out[6 * s + 0] = c.LX * c.R;
         out[6 * s + 1] = c.NW * (64 / c.LX) * c.C;
         out[6 * s + 2] = c.NW;
@@ -987,14 +1257,17 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
     for (int s = sc; s >= 0; --s) {
         const int lw = P.ws[s], lh = P.hs[s], lp = P.pitch[s];
         const size_t plane = P.plane[s];
-        const TilePick tp = K0 > 0 ? pick_tiles(lw, lh, K0, (unsigned)p->tile_mask) : pick_tiles_auto(lw, lh, p->iters, (unsigned)p->tile_mask);
+        const unsigned tmask = (unsigned)p->tile_mask & (unsigned)(kStreamBit - 1);
+        const TilePick tp = K0 > 0 ? pick_tiles(lw, lh, K0, tmask) : pick_tiles_auto(lw, lh, p->iters, tmask);
+        const bool strm = level_streams(p, eps, s, lw, lh, plane);
+        const int perm = strm ? 0 : 1;
         if (lp != lw) {
-            k_zero_pad<<<dim3(va_cdiv((lp - lw) * lh * kNF_RO, TPB), P.NP), TPB, 0, st>>>(ro, kNF_RO, lw, lh, lp, plane);
+            k_zero_pad<<<dim3(va_cdiv((lp - lw) * lh * kNF_RO, TPB), P.NP), TPB, 0, st>>>(ro, kNF_RO, lw, lh, lp, plane, perm);
             VA_LAUNCH_CHECK();
         }
         // the pairs of a level go through its warps x iterations in chunks (cache residency: chunk_pairs); every chunk
         // starts from the level's entry buffer index and ends on the same one
-        const int cp = (eps || !VA_CHUNK) ? P.NP : chunk_pairs(lw, lh, tp, P.NP);
+        const int cp = (eps || !VA_CHUNK || strm) ? P.NP : chunk_pairs(lw, lh, tp, P.NP);
         const int cur_in = cur;
         for (int c0 = 0; c0 < P.NP; c0 += cp) {
         const int nc = P.NP - c0 < cp ? P.NP - c0 : cp;
@@ -1002,7 +1275,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
         cur = cur_in;
         for (int wp = 0; wp < p->warps; ++wp) {
             k_warp<<<gpc, TPB, 0, st>>>(pyr[s], plane, lw, lh, lp, P.F, state[0], state[1], eps ? sel : nullptr, cur,
-                                         eps ? base : nullptr, ro, c0);
+                                         eps ? base : nullptr, ro, c0, perm);
             VA_LAUNCH_CHECK();
             if (eps) VA_HIP(hipMemsetAsync(err, 0, (size_t)P.NP * p->iters * sizeof(unsigned long long), st));
             va_prof_span span{};
@@ -1033,10 +1306,38 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
             a.theta = p->theta;
             a.pair0 = c0;
             int launches = 0;
-            for (int it = 0; it < p->iters;) {
+            if (strm) {
+                const StreamPick sp = pick_stream(lw, lh, nc);
+                StreamArgs sa{};
+                sa.ro = ro;
+                sa.plane = plane;
+                sa.w = lw;
+                sa.h = lh;
+                sa.pitch = lp;
+                sa.nsx = sp.nsx;
+                sa.nch = sp.nch;
+                sa.R = sp.R;
+                sa.HX = sp.HX;
+                sa.pair0 = c0;
+                sa.l_t = a.l_t;
+                sa.taut = a.taut;
+                sa.theta = a.theta;
+                const dim3 grid(sp.nsx * sp.nch, nc);
+                for (int it = 0; it < p->iters; it += kStreamK) {
+                    sa.K = (p->iters - it) < kStreamK ? (p->iters - it) : kStreamK;
+                    sa.sin = state[cur];
+                    sa.sout = state[cur ^ 1];
+                    sa.rev = VA_REV ? (launches & 1) : 0;
+                    if (p->fast_math) k_iter_stream<kStreamK, true><<<grid, 64, 0, st>>>(sa);
+                    else k_iter_stream<kStreamK, false><<<grid, 64, 0, st>>>(sa);
+                    cur ^= 1;
+                    ++launches;
+                }
+            }
+            for (int it = strm ? p->iters : 0; it < p->iters;) {
                 // the tile grid depends on the halo depth: a shorter last launch gets its own grid
                 const int k = (p->iters - it) < tp.K ? (p->iters - it) : tp.K;
-                const TilePick tk = (k == tp.K) ? tp : pick_tiles(lw, lh, k, (unsigned)p->tile_mask);
+                const TilePick tk = (k == tp.K) ? tp : pick_tiles(lw, lh, k, tmask);
                 a.ntx = tk.ntx;
                 a.nty = tk.nty;
                 a.HX = tk.HX;
@@ -1069,9 +1370,10 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
             // ro is free between levels: use it as the upsampling target (2 of its 4 planes per pair)
             const dim3 g(va_cdiv(P.ws[s - 1] * P.hs[s - 1], TPB), P.NP);
             k_upsample<<<g, TPB, 0, st>>>(state[0], state[1], eps ? sel : nullptr, cur, lw, lh, lp, plane, ro, P.ws[s - 1],
-                                           P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1], 1.0f / p->scale_step);
+                                           P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1], 1.0f / p->scale_step, perm);
+            const int fperm = level_streams(p, eps, s - 1, P.ws[s - 1], P.hs[s - 1], P.plane[s - 1]) ? 0 : 1;
             const dim3 gi(va_cdiv(P.pitch[s - 1] * P.hs[s - 1], TPB), P.NP);
-            k_level_init<<<gi, TPB, 0, st>>>(ro, state[0], P.ws[s - 1], P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1]);
+            k_level_init<<<gi, TPB, 0, st>>>(ro, state[0], P.ws[s - 1], P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1], fperm);
             VA_LAUNCH_CHECK();
             cur = 0;
             if (eps) VA_HIP(hipMemsetAsync(sel, 0, (size_t)P.NP * sizeof(int), st));
@@ -1079,7 +1381,8 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
     }
     {
         const dim3 g(va_cdiv(w * h, TPB), P.NP);
-        k_flow_out<<<g, TPB, 0, st>>>(state[0], state[1], eps ? sel : nullptr, cur, w, h, P.pitch[0], P.plane[0], (float*)flow);
+        k_flow_out<<<g, TPB, 0, st>>>(state[0], state[1], eps ? sel : nullptr, cur, w, h, P.pitch[0], P.plane[0], (float*)flow,
+                                       level_streams(p, eps, 0, w, h, P.plane[0]) ? 0 : 1);
         VA_LAUNCH_CHECK();
     }
     return VA_OK;
