@@ -672,11 +672,20 @@ struct StreamArgs {
     float l_t, taut, theta;
 };
 
-template <int KS, bool FAST>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_iter_stream(StreamArgs a)
+// KH levels per wave, NWV waves per workgroup.  NWV = 1: the wave is the whole pipeline (K <= KH iterations per pass).
+// NWV = 2: the second wave continues where the first stops -- it takes the rows that leave the first wave's level
+// KH-1 out of a double-buffered LDS row instead of HBM and carries them through levels KH .. 2KH-1, so that one pass
+// over the strip is worth K <= 2 KH iterations of HBM traffic; both waves share the ring of per-warp constants; one
+// workgroup barrier per step keeps them a step apart.
+template <int KH, int NWV, bool FAST>
+__global__ void __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_iter_stream(StreamArgs a)
 {
-    constexpr int NR = KS - 1;  // ring rows: level t >= 1 reads row s - t; row s is written at the end of step s
-    __shared__ f2 ring[NR][kNF_RO][64];
+    // ring rows: NWV = 1: level t >= 1 reads row s - t, row s is written at the end of step s.  NWV = 2: the first
+    // wave writes row s - 1 at the start of step s (after the barrier), the oldest row read in step s is
+    // s - (KH + 1) - (KH - 1) = s - 2 KH.
+    constexpr int NRING = NWV == 1 ? KH - 1 : NWV * KH;
+    __shared__ f2 ring[NRING][kNF_RO][64];
+    __shared__ f2 iface[NWV > 1 ? NWV - 1 : 1][2][kNF_STATE][64];
 
     unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
     {
@@ -687,7 +696,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int pair = a.pair0 + (int)(lid / gridDim.x), job = (int)(lid % gridDim.x);
     const int sx = job % a.nsx, ch = job / a.nsx;
     const int w = a.w, h = a.h, pitch = a.pitch, K = a.K;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ox = sx * (128 - 2 * a.HX);
     const int vx0 = ox + (sx > 0 ? a.HX : 0), vx1 = (sx == a.nsx - 1) ? pitch : ox + 128 - a.HX;
     const int x0 = ox + 2 * lane;
@@ -713,160 +723,221 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const float l_t = a.l_t;
     const f2 taut = splat(a.taut), theta = splat(a.theta), one = splat(1.0f), zero = splat(0.0f);
 
-#pragma clang loop unroll(full)
-    for (int r = 0; r < NR; ++r)
+    for (int r = wv; r < NRING; r += NWV)
 #pragma clang loop unroll(full)
         for (int f = 0; f < kNF_RO; ++f) ring[r][f][lane] = zero;
-
-    f2 P11[KS], P12[KS], P21[KS], P22[KS], U1[KS], U2[KS];
+    if constexpr (NWV > 1) {
+        if (wv == 0)
 #pragma clang loop unroll(full)
-    for (int t = 0; t < KS; ++t) P11[t] = P12[t] = P21[t] = P22[t] = U1[t] = U2[t] = zero;
+            for (int f = 0; f < kNF_STATE; ++f) iface[0][0][f][lane] = iface[0][1][f][lane] = zero;
+        __syncthreads();
+    }
 
     auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int f, int y) -> f2 {
         return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, loff, f * planeb + y * pitchb, 0));
     };
     auto st = [&](f2 v, int f, int y) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), rs_out, loff, f * planeb + y * pitchb, 0); };
-    f2 nst[kNF_STATE], nro[kNF_RO];
-    {
-        const int y = ys < ye ? ys : 0;  // (an empty chunk cannot occur: b0 > a0)
-#pragma clang loop unroll(full)
-        for (int f = 0; f < kNF_STATE; ++f) nst[f] = ld(rs_in, f, y);
-#pragma clang loop unroll(full)
-        for (int f = 0; f < kNF_RO; ++f) nro[f] = ld(rs_ro, f, y);
-    }
 
-    const int nsteps = b0 - ys + K;  // level K-1 emits row b0-1 when row b0 (or the dummy row h) comes in
-    auto step = [&](const int s, auto steady_tag) __attribute__((always_inline)) {
-        constexpr bool STEADY = decltype(steady_tag)::value;
-        f2 c_u1 = nst[0], c_u2 = nst[1], c_p11 = nst[2], c_p12 = nst[3], c_p21 = nst[4], c_p22 = nst[5];
-        const f2 r0[kNF_RO] = {nro[0], nro[1], nro[2], nro[3]};
-        {
-            // next row (beyond the last row of the strip: row ye - 1 again -- finite values nobody uses, or, at the image
-            // bottom, the dummy row h whose only consumer multiplies its difference by my = 0)
-            const int rn = d_min(ys + s + 1, ye - 1);
+    // level K-1 (in the last wave) emits row b0-1 when row b0 (or the dummy row h) comes in; every wave boundary adds a step
+    const int nsteps = b0 - ys + K + (NWV - 1);
+
+    auto run = [&](auto wave_tag) __attribute__((always_inline)) {
+        constexpr int W = decltype(wave_tag)::value;
+        constexpr bool FIRST = W == 0, LAST = W == NWV - 1;
+        constexpr int G0 = W * KH, LAG = W * (KH + 1);  // first level of this wave; steps it runs behind the first wave
+
+        f2 P11[KH], P12[KH], P21[KH], P22[KH], U1[KH], U2[KH];
 #pragma clang loop unroll(full)
-            for (int f = 0; f < kNF_STATE; ++f) nst[f] = ld(rs_in, f, rn);
+        for (int t = 0; t < KH; ++t) P11[t] = P12[t] = P21[t] = P22[t] = U1[t] = U2[t] = zero;
+        f2 nst[kNF_STATE], nro[kNF_RO], rprev[kNF_RO] = {zero, zero, zero, zero};
 #pragma clang loop unroll(full)
-            for (int f = 0; f < kNF_RO; ++f) nro[f] = ld(rs_ro, f, rn);
-            __builtin_amdgcn_sched_barrier(0);  // the loads stay at the top of the step: a whole step hides their latency
-        }
-        // One level: phase A on the incoming row C (k_iter_tile's arithmetic, operation for operation), phase B on the
-        // row above it (whose lower neighbour is the row just computed); the level keeps the incoming p and the new u,
-        // and passes on (its old u, the new p) = the time-(t+1) values of the row above.
-        auto level = [&](int t, const f2 wx, const f2 wy, const f2 rc, const f2 ig, const f2 my) __attribute__((always_inline)) {
-            const float l11 = dpp_from_left(c_p11.y), l21 = dpp_from_left(c_p21.y);
-            const f2 dx11 = f2{sub_s(c_p11.x, l11), sub_s(c_p11.y, c_p11.x)};
-            const f2 dx21 = f2{sub_s(c_p21.x, l21), sub_s(c_p21.y, c_p21.x)};
-            const f2 div1 = dx11 + (c_p12 - P12[t]);
-            const f2 div2 = dx21 + (c_p22 - P22[t]);
-            const f2 rho = pk_fma(wy, c_u2, pk_fma(wx, c_u1, rc));
-            const f2 tt = -rho * ig;
-            const f2 fi = f2{__builtin_amdgcn_fmed3f(tt.x, -l_t, l_t), __builtin_amdgcn_fmed3f(tt.y, -l_t, l_t)};
-            const f2 v1 = pk_fma(fi, wx, c_u1);
-            const f2 v2 = pk_fma(fi, wy, c_u2);
-            const f2 n1 = pk_fma(theta, div1, v1);
-            const f2 n2 = pk_fma(theta, div2, v2);
-            const float r1 = dpp_from_right(U1[t].x), r2 = dpp_from_right(U2[t].x);
-            const f2 d1x = f2{sub_s(U1[t].y, U1[t].x), sub_s(r1, U1[t].y)};
-            const f2 d2x = f2{sub_s(U2[t].y, U2[t].x), sub_s(r2, U2[t].y)};
-            const f2 u1x = d1x * mx, u1y = (n1 - U1[t]) * my;
-            const f2 u2x = d2x * mx, u2y = (n2 - U2[t]) * my;
-            const f2 s1 = pk_fma(u1y, u1y, pk_fma(u1x, u1x, splat(kSqrtReg)));
-            const f2 s2 = pk_fma(u2y, u2y, pk_fma(u2x, u2x, splat(kSqrtReg)));
-            f2 q1, q2;
-            if constexpr (FAST) {
-                const f2 g1 = f2{__builtin_amdgcn_sqrtf(s1.x), __builtin_amdgcn_sqrtf(s1.y)};
-                const f2 g2 = f2{__builtin_amdgcn_sqrtf(s2.x), __builtin_amdgcn_sqrtf(s2.y)};
-                const f2 d1 = pk_fma(taut, g1, one), d2 = pk_fma(taut, g2, one);
-                q1 = f2{__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)};
-                q2 = f2{__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)};
-            } else {
-                const f2 g1 = sqrt_exact_pk(s1), g2 = sqrt_exact_pk(s2);
-                const f2 d1 = pk_fma(taut, g1, one), d2 = pk_fma(taut, g2, one);
-                const f2 rinv = rcp_exact_pk(d1 * d2);
-                q1 = d2 * rinv;
-                q2 = d1 * rinv;
-            }
-            const f2 o11 = pk_fma(taut, u1x, P11[t]) * q1;
-            const f2 o12 = pk_fma(taut, u1y, P12[t]) * q1;
-            const f2 o21 = pk_fma(taut, u2x, P21[t]) * q2;
-            const f2 o22 = pk_fma(taut, u2y, P22[t]) * q2;
-            const f2 ou1 = U1[t], ou2 = U2[t];
-            P11[t] = c_p11;
-            P12[t] = c_p12;
-            P21[t] = c_p21;
-            P22[t] = c_p22;
-            U1[t] = n1;
-            U2[t] = n2;
-            c_u1 = ou1;
-            c_u2 = ou2;
-            c_p11 = o11;
-            c_p12 = o12;
-            c_p21 = o21;
-            c_p22 = o22;
-        };
-        bool emitted;
-        // levels in flight: tmin .. tmax (level t takes the rows [a0 - (K - t), b0 + (K - t)) of the image and, at
-        // the image bottom, the dummy row h; with rin = ys + s - t that is a contiguous range of t)
-        const int rs = ys + s, s0 = s % NR;  // row s of the strip lives in ring slot s % NR
-        const int tmin = d_max(0, rs - h), tmax = d_min(d_min(K - 1, rs), (rs - a0 + K) >> 1);
-        if constexpr (STEADY) {
-            // steady state: every level works, no row is the image's last: straight-line code
-            // the constants of level t + 1 are fetched from the ring while level t computes
-            f2 q[kNF_RO] = {r0[0], r0[1], r0[2], r0[3]};
+        for (int f = 0; f < kNF_STATE; ++f) nst[f] = FIRST ? ld(rs_in, f, ys) : zero;
 #pragma clang loop unroll(full)
-            for (int t = 0; t < KS; ++t) {
-                f2 nq[kNF_RO] = {zero, zero, zero, zero};
-                if (t + 1 < KS) {
-                    const int slot = s0 - (t + 1) < 0 ? s0 - (t + 1) + NR : s0 - (t + 1);
+        for (int f = 0; f < kNF_RO; ++f) nro[f] = FIRST ? ld(rs_ro, f, ys) : zero;
+
+        auto step = [&](const int s, auto steady_tag) __attribute__((always_inline)) {
+            constexpr bool STEADY = decltype(steady_tag)::value;
+            const int s0 = s % NRING;  // row s of the strip lives in ring slot s % NRING
+            f2 c_u1, c_u2, c_p11, c_p12, c_p21, c_p22;
+            f2 r0[kNF_RO] = {zero, zero, zero, zero};
+            if constexpr (FIRST) {
+                c_u1 = nst[0], c_u2 = nst[1], c_p11 = nst[2], c_p12 = nst[3], c_p21 = nst[4], c_p22 = nst[5];
 #pragma clang loop unroll(full)
-                    for (int f = 0; f < kNF_RO; ++f) nq[f] = ring[slot][f][lane];
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int f = 0; f < kNF_RO; ++f) r0[f] = nro[f];
+                // next row (beyond the last row of the strip: row ye - 1 again -- finite values nobody uses, or, at the
+                // image bottom, the dummy row h whose only consumer multiplies its difference by my = 0)
+                const int rn = d_min(ys + s + 1, ye - 1);
+#pragma clang loop unroll(full)
+                for (int f = 0; f < kNF_STATE; ++f) nst[f] = ld(rs_in, f, rn);
+#pragma clang loop unroll(full)
+                for (int f = 0; f < kNF_RO; ++f) nro[f] = ld(rs_ro, f, rn);
+                if constexpr (NWV > 1) {  // the constants of row s - 1 go into the ring now that the barrier has passed
+                    const int sl = s0 == 0 ? NRING - 1 : s0 - 1;
+#pragma clang loop unroll(full)
+                    for (int f = 0; f < kNF_RO; ++f) ring[sl][f][lane] = rprev[f];
                 }
-                level(t, q[0], q[1], q[2], q[3], one);
-#pragma clang loop unroll(full)
-                for (int f = 0; f < kNF_RO; ++f) q[f] = nq[f];
+                __builtin_amdgcn_sched_barrier(0);  // the loads stay at the top of the step: a whole step hides their latency
+            } else {
+                const int bsel = (s + 1) & 1;  // what the wave before wrote in step s - 1
+                c_u1 = iface[W - 1][bsel][0][lane];
+                c_u2 = iface[W - 1][bsel][1][lane];
+                c_p11 = iface[W - 1][bsel][2][lane];
+                c_p12 = iface[W - 1][bsel][3][lane];
+                c_p21 = iface[W - 1][bsel][4][lane];
+                c_p22 = iface[W - 1][bsel][5][lane];
             }
-            emitted = true;
-        } else {
-            emitted = false;
+            // One level: phase A on the incoming row C (k_iter_tile's arithmetic, operation for operation), phase B on the
+            // row above it (whose lower neighbour is the row just computed); the level keeps the incoming p and the new u,
+            // and passes on (its old u, the new p) = the time-(t+1) values of the row above.
+            auto level = [&](int t, const f2 wx, const f2 wy, const f2 rc, const f2 ig, const f2 my) __attribute__((always_inline)) {
+                const float l11 = dpp_from_left(c_p11.y), l21 = dpp_from_left(c_p21.y);
+                const f2 dx11 = f2{sub_s(c_p11.x, l11), sub_s(c_p11.y, c_p11.x)};
+                const f2 dx21 = f2{sub_s(c_p21.x, l21), sub_s(c_p21.y, c_p21.x)};
+                const f2 div1 = dx11 + (c_p12 - P12[t]);
+                const f2 div2 = dx21 + (c_p22 - P22[t]);
+                const f2 rho = pk_fma(wy, c_u2, pk_fma(wx, c_u1, rc));
+                const f2 tt = -rho * ig;
+                const f2 fi = f2{__builtin_amdgcn_fmed3f(tt.x, -l_t, l_t), __builtin_amdgcn_fmed3f(tt.y, -l_t, l_t)};
+                const f2 v1 = pk_fma(fi, wx, c_u1);
+                const f2 v2 = pk_fma(fi, wy, c_u2);
+                const f2 n1 = pk_fma(theta, div1, v1);
+                const f2 n2 = pk_fma(theta, div2, v2);
+                const float r1 = dpp_from_right(U1[t].x), r2 = dpp_from_right(U2[t].x);
+                const f2 d1x = f2{sub_s(U1[t].y, U1[t].x), sub_s(r1, U1[t].y)};
+                const f2 d2x = f2{sub_s(U2[t].y, U2[t].x), sub_s(r2, U2[t].y)};
+                const f2 u1x = d1x * mx, u1y = (n1 - U1[t]) * my;
+                const f2 u2x = d2x * mx, u2y = (n2 - U2[t]) * my;
+                const f2 s1 = pk_fma(u1y, u1y, pk_fma(u1x, u1x, splat(kSqrtReg)));
+                const f2 s2 = pk_fma(u2y, u2y, pk_fma(u2x, u2x, splat(kSqrtReg)));
+                f2 q1, q2;
+                if constexpr (FAST) {
+                    const f2 g1 = f2{__builtin_amdgcn_sqrtf(s1.x), __builtin_amdgcn_sqrtf(s1.y)};
+                    const f2 g2 = f2{__builtin_amdgcn_sqrtf(s2.x), __builtin_amdgcn_sqrtf(s2.y)};
+                    const f2 d1 = pk_fma(taut, g1, one), d2 = pk_fma(taut, g2, one);
+                    q1 = f2{__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)};
+                    q2 = f2{__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)};
+                } else {
+                    const f2 g1 = sqrt_exact_pk(s1), g2 = sqrt_exact_pk(s2);
+                    const f2 d1 = pk_fma(taut, g1, one), d2 = pk_fma(taut, g2, one);
+                    const f2 rinv = rcp_exact_pk(d1 * d2);
+                    q1 = d2 * rinv;
+                    q2 = d1 * rinv;
+                }
+                const f2 o11 = pk_fma(taut, u1x, P11[t]) * q1;
+                const f2 o12 = pk_fma(taut, u1y, P12[t]) * q1;
+                const f2 o21 = pk_fma(taut, u2x, P21[t]) * q2;
+                const f2 o22 = pk_fma(taut, u2y, P22[t]) * q2;
+                const f2 ou1 = U1[t], ou2 = U2[t];
+                P11[t] = c_p11;
+                P12[t] = c_p12;
+                P21[t] = c_p21;
+                P22[t] = c_p22;
+                U1[t] = n1;
+                U2[t] = n2;
+                c_u1 = ou1;
+                c_u2 = ou2;
+                c_p11 = o11;
+                c_p12 = o12;
+                c_p21 = o21;
+                c_p22 = o22;
+            };
+            // ring slot of the constants of level t's incoming row, s - LAG - t
+            auto slot_of = [&](int t) {
+                const int c = (LAG + t) % NRING;
+                return s0 - c < 0 ? s0 - c + NRING : s0 - c;
+            };
+            const int rs = ys + s - LAG;  // the row coming into this wave's first level
+            bool emitted;
+            if constexpr (STEADY) {
+                // every level of the wave works and no row is the image's last: straight-line code; the constants of
+                // level t + 1 are fetched from the ring while level t computes
+                f2 q[kNF_RO] = {r0[0], r0[1], r0[2], r0[3]};
+                if constexpr (!FIRST) {
+                    const int slot = slot_of(0);
 #pragma clang loop unroll(full)
-            for (int t = 0; t < KS; ++t) {
-                const bool act = t >= tmin && t <= tmax;
-                if (t == K - 1) emitted = act;
-                if (act) {
-                    const int rin = rs - t;  // the row coming into level t
-                    const f2 my = splat(rin - 1 < h - 1 ? 1.0f : 0.0f);
-                    if (t == 0) {
-                        level(0, r0[0], r0[1], r0[2], r0[3], my);
-                    } else {
-                        const int slot = s0 - t < 0 ? s0 - t + NR : s0 - t;
-                        level(t, ring[slot][0][lane], ring[slot][1][lane], ring[slot][2][lane], ring[slot][3][lane], my);
+                    for (int f = 0; f < kNF_RO; ++f) q[f] = ring[slot][f][lane];
+                }
+#pragma clang loop unroll(full)
+                for (int t = 0; t < KH; ++t) {
+                    f2 nq[kNF_RO] = {zero, zero, zero, zero};
+                    if (t + 1 < KH) {
+                        const int slot = slot_of(t + 1);
+#pragma clang loop unroll(full)
+                        for (int f = 0; f < kNF_RO; ++f) nq[f] = ring[slot][f][lane];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    level(t, q[0], q[1], q[2], q[3], one);
+#pragma clang loop unroll(full)
+                    for (int f = 0; f < kNF_RO; ++f) q[f] = nq[f];
+                }
+                emitted = true;
+            } else {
+                emitted = false;
+#pragma clang loop unroll(full)
+                for (int t = 0; t < KH; ++t) {
+                    // global level g takes the rows [a0 - (K - g), b0 + (K - g)) of the image and, at the image bottom,
+                    // the dummy row h
+                    const int g = G0 + t, rin = rs - t;
+                    const int lo = d_max(0, a0 - (K - g)), hi = d_min(h, b0 + (K - g) - 1);
+                    const bool act = g < K && rin >= lo && rin <= hi;
+                    if (g == K - 1) emitted = act;
+                    if (act) {
+                        const f2 my = splat(rin - 1 < h - 1 ? 1.0f : 0.0f);
+                        if (FIRST && t == 0) {
+                            level(0, r0[0], r0[1], r0[2], r0[3], my);
+                        } else {
+                            const int slot = slot_of(t);
+                            level(t, ring[slot][0][lane], ring[slot][1][lane], ring[slot][2][lane], ring[slot][3][lane], my);
+                        }
                     }
                 }
             }
-        }
-        const int rout = ys + s - K;  // the row that left level K-1 in this step, K iterations on
-        if (emitted && stok && rout >= a0 && rout < b0) {
-            st(c_u1, 0, rout);
-            st(c_u2, 1, rout);
-            st(c_p11, 2, rout);
-            st(c_p12, 3, rout);
-            st(c_p21, 4, rout);
-            st(c_p22, 5, rout);
-        }
-        {
+            if constexpr (LAST) {
+                const int rout = ys + s - W - K;  // the row that left level K-1 in this step, K iterations on
+                if (emitted && stok && rout >= a0 && rout < b0) {
+                    st(c_u1, 0, rout);
+                    st(c_u2, 1, rout);
+                    st(c_p11, 2, rout);
+                    st(c_p12, 3, rout);
+                    st(c_p21, 4, rout);
+                    st(c_p22, 5, rout);
+                }
+            } else {
+                const int bsel = s & 1;
+                iface[W][bsel][0][lane] = c_u1;
+                iface[W][bsel][1][lane] = c_u2;
+                iface[W][bsel][2][lane] = c_p11;
+                iface[W][bsel][3][lane] = c_p12;
+                iface[W][bsel][4][lane] = c_p21;
+                iface[W][bsel][5][lane] = c_p22;
+            }
+            if constexpr (FIRST) {
+                if constexpr (NWV == 1) {
 #pragma clang loop unroll(full)
-            for (int f = 0; f < kNF_RO; ++f) ring[s0][f][lane] = r0[f];
-        }
+                    for (int f = 0; f < kNF_RO; ++f) ring[s0][f][lane] = r0[f];
+                } else {
+#pragma clang loop unroll(full)
+                    for (int f = 0; f < kNF_RO; ++f) rprev[f] = r0[f];
+                }
+            }
+            // hand-over barrier: LDS traffic only (no wait for the global loads in flight or the stores just issued)
+            if constexpr (NWV > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        // steady state of this wave: steps [s_a, s_b) (all its KH levels inside their row windows, below the last row)
+        int s_a = d_max(KH - 1, a0 - K + G0 + 2 * KH - 2) - ys + LAG;
+        int s_b = d_min(nsteps, d_min(h - 1, b0 + K - G0 - 1) - ys + LAG + 1);
+        if (K < G0 + KH || s_a > s_b) s_a = s_b = 0;
+        int s = 0;
+        for (; s < s_a; ++s) step(s, std::false_type{});
+        for (; s < s_b; ++s) step(s, std::true_type{});
+        for (; s < nsteps; ++s) step(s, std::false_type{});
     };
-    // steady state (every level at work, no level at the image's last row): steps [s_a, s_b)
-    int s_a = d_max(KS - 1, a0 + KS - 2) - ys, s_b = d_min(nsteps, h - ys);
-    if (K != KS || s_a > s_b) s_a = s_b = 0;
-    int s = 0;
-    for (; s < s_a; ++s) step(s, std::false_type{});
-    for (; s < s_b; ++s) step(s, std::true_type{});
-    for (; s < nsteps; ++s) step(s, std::false_type{});
+    if constexpr (NWV == 1) {
+        run(std::integral_constant<int, 0>{});
+    } else {
+        if (wv == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, NWV - 1>{});
+    }
 }
 
 // ---------------------------------------------------------------- host side -------------------
@@ -980,7 +1051,8 @@ void launch_iter(const TilePick& tp, const IterArgs& a, int npairs, hipStream_t 
 }
 
 // ---- k_iter_stream: strips x chunks of a level
-constexpr int kStreamK = 10;        // pipeline depth the kernel is compiled for (300 = 30 x 10)
+constexpr int kStreamK1 = 10;       // one-wave pipeline: iterations per pass
+constexpr int kStreamKH2 = 8;       // two-wave pipeline: levels per wave (16 iterations per pass)
 constexpr int kStreamBit = 1 << 8;  // va_tvl1_params.tile_mask bit: iterate with k_iter_stream
 struct StreamPick {
     int nsx, nch, R, HX;
@@ -990,10 +1062,12 @@ int stream_env(const char* name, int dflt)
     const char* e = getenv(name);
     return e && *e ? atoi(e) : dflt;
 }
+// iterations per pass: 16 (two waves, an LDS hand-over between them) unless VA_STREAM2=0 (experiment switch)
+int stream_depth() { return stream_env("VA_STREAM2", 1) ? 2 * kStreamKH2 : kStreamK1; }
 StreamPick pick_stream(int w, int h, int npairs)
 {
     StreamPick sp{};
-    sp.HX = kStreamK;  // even: strip origins stay 8-byte aligned
+    sp.HX = stream_depth();  // even: strip origins stay 8-byte aligned
     sp.nsx = tiles_1d(w, 128, sp.HX);
     // chunks: about one job per two wave slots of the GPU (256 CUs x 8; measured best with one and with two concurrent
     // calls on different HIP streams), rows per chunk not below 32
@@ -1017,7 +1091,7 @@ bool level_streams(const va_tvl1_params* p, bool eps, int s, int w, int h, size_
     if (p->tile_mask != 0) return false;
     const int env = stream_env("VA_STREAM", -1);
     if (env >= 0) return ((env >> s) & 1) != 0;
-    const int nsx = tiles_1d(w, 128, kStreamK);
+    const int nsx = tiles_1d(w, 128, stream_depth());
     return (double)w >= 0.8 * 128.0 * nsx && (double)w * h >= 40000.0;
 }
 
@@ -1170,7 +1244,7 @@ extern "C" int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out
         const TileCfg& c = kCfgs[tp.cfg];
         const int lp = (ws[s] + 3) / 4 * 4;
         if (level_streams(p, p->epsilon > 0.0f, s, ws[s], hs[s], va_align_up((size_t)lp * hs[s], 64))) {
-            const int plan[6] = {128, 0, 1, kStreamK, tiles_1d(ws[s], 128, kStreamK), 0};
+            const int plan[6] = {128, 0, stream_depth() > kStreamK1 ? 2 : 1, stream_depth(), tiles_1d(ws[s], 128, stream_depth()), 0};
             memcpy(out + 6 * s, plan, sizeof(plan));
             continue;
         }
@@ -1323,14 +1397,23 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                 sa.taut = a.taut;
                 sa.theta = a.theta;
                 const dim3 grid(sp.nsx * sp.nch, nc);
-                for (int it = 0; it < p->iters; it += kStreamK) {
-                    sa.K = (p->iters - it) < kStreamK ? (p->iters - it) : kStreamK;
+                const bool two = stream_depth() > kStreamK1;
+                for (int it = 0; it < p->iters;) {
+                    const int rem = p->iters - it;
+                    const bool w2 = two && rem > kStreamKH2;  // the two-wave kernel needs its last level in the second wave
+                    sa.K = w2 ? (rem < 2 * kStreamKH2 ? rem : 2 * kStreamKH2) : (rem < kStreamK1 ? rem : kStreamK1);
                     sa.sin = state[cur];
                     sa.sout = state[cur ^ 1];
                     sa.rev = VA_REV ? (launches & 1) : 0;
-                    if (p->fast_math) k_iter_stream<kStreamK, true><<<grid, 64, 0, st>>>(sa);
-                    else k_iter_stream<kStreamK, false><<<grid, 64, 0, st>>>(sa);
+                    if (w2) {
+                        if (p->fast_math) k_iter_stream<kStreamKH2, 2, true><<<grid, 128, 0, st>>>(sa);
+                        else k_iter_stream<kStreamKH2, 2, false><<<grid, 128, 0, st>>>(sa);
+                    } else {
+                        if (p->fast_math) k_iter_stream<kStreamK1, 1, true><<<grid, 64, 0, st>>>(sa);
+                        else k_iter_stream<kStreamK1, 1, false><<<grid, 64, 0, st>>>(sa);
+                    }
                     cur ^= 1;
+                    it += sa.K;
                     ++launches;
                 }
             }
