@@ -70,11 +70,14 @@ def test_tile_plan_of_the_benchmark_pyramid():
     224x224 benchmark pyramid in fixed-iteration mode, and the epsilon mode's forced block depth 1."""
     from video_analytics_amd import _ffi, flow
     plan = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0))
-    # the 224^2 level streams (two 128-column strips, 10 iterations per pass); the levels below use register tiles
-    assert (plan[0]["tile_w"], plan[0]["tile_h"], plan[0]["waves"], plan[0]["block_iters"], plan[0]["tiles_x"]) == (128, 0, 1, 10, 2)
+    # the 224^2 level streams (two 128-column strips, two waves, 16 iterations per pass); the levels below use register tiles
+    assert (plan[0]["tile_w"], plan[0]["tile_h"], plan[0]["waves"], plan[0]["block_iters"], plan[0]["tiles_x"]) == (128, 0, 2, 16, 2)
     assert [d["tile_h"] > 0 for d in plan[1:]] == [True] * 4
     everywhere = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 8))
     assert [(d["tile_w"], d["tiles_x"]) for d in everywhere] == [(128, 2), (128, 2), (128, 2), (128, 1), (128, 1)]
+    hd = flow.tile_plan(1280, 720, _ffi.default_tvl1_params(epsilon=0.0))  # wide levels: one wave, 10 per pass, halo 10
+    assert [(d["tile_w"], d["waves"], d["block_iters"], d["tiles_x"]) for d in hd] == [
+        (128, 1, 10, 12), (128, 1, 10, 10), (128, 1, 10, 8), (128, 1, 10, 6), (128, 1, 10, 5)]
     plan = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=0xFF))  # register tiles only
     assert [(d["tile_w"], d["tile_h"], d["waves"], d["block_iters"]) for d in plan] == [
         (64, 64, 4, 12), (64, 64, 4, 12), (64, 64, 4, 12), (128, 64, 8, 7), (64, 64, 4, 16)]

@@ -1055,23 +1055,30 @@ constexpr int kStreamK1 = 10;       // one-wave pipeline: iterations per pass
 constexpr int kStreamKH2 = 8;       // two-wave pipeline: levels per wave (16 iterations per pass)
 constexpr int kStreamBit = 1 << 8;  // va_tvl1_params.tile_mask bit: iterate with k_iter_stream
 struct StreamPick {
-    int nsx, nch, R, HX;
+    int nsx, nch, R, HX, two;
 };
 int stream_env(const char* name, int dflt)
 {
     const char* e = getenv(name);
     return e && *e ? atoi(e) : dflt;
 }
-// iterations per pass: 16 (two waves, an LDS hand-over between them) unless VA_STREAM2=0 (experiment switch)
-int stream_depth() { return stream_env("VA_STREAM2", 1) ? 2 * kStreamKH2 : kStreamK1; }
+// Strips of a level.  Two-wave pipeline (16 iterations per pass) where the deeper x halo costs nothing, i.e. where the
+// level has no interior strip (w <= 224); wider levels use the one-wave pipeline (10 per pass, halo 10: measured on
+// the 1280x720 pyramid).  VA_STREAM2=0 (experiment switch): one-wave everywhere.
+void stream_strips(int w, StreamPick& sp)
+{
+    sp.two = stream_env("VA_STREAM2", 1) != 0 && tiles_1d(w, 128, 2 * kStreamKH2) <= 2;
+    sp.HX = sp.two ? 2 * kStreamKH2 : kStreamK1;  // even: strip origins stay 8-byte aligned
+    sp.nsx = tiles_1d(w, 128, sp.HX);
+}
 StreamPick pick_stream(int w, int h, int npairs)
 {
     StreamPick sp{};
-    sp.HX = stream_depth();  // even: strip origins stay 8-byte aligned
-    sp.nsx = tiles_1d(w, 128, sp.HX);
-    // chunks: about one job per two wave slots of the GPU (256 CUs x 8; measured best with one and with two concurrent
-    // calls on different HIP streams), rows per chunk not below 32
-    const int slots = stream_env("VA_STREAM_SLOTS", 1024);
+    stream_strips(w, sp);
+    // chunks of rows: the number of jobs (strip x chunk x pair) that keeps the GPU busiest was measured with one and
+    // with two concurrent calls on different HIP streams: ~1024 one-wave jobs, ~640 two-wave jobs per call (256 CUs x
+    // 8 waves); rows per chunk not below 32
+    const int slots = stream_env("VA_STREAM_SLOTS", sp.two ? 640 : 1024);
     int nch = stream_env("VA_STREAM_NCH", 0);
     if (nch <= 0) nch = (int)((double)slots / ((double)npairs * sp.nsx) + 0.5);
     if (nch > h / 32) nch = h / 32;
@@ -1091,8 +1098,9 @@ bool level_streams(const va_tvl1_params* p, bool eps, int s, int w, int h, size_
     if (p->tile_mask != 0) return false;
     const int env = stream_env("VA_STREAM", -1);
     if (env >= 0) return ((env >> s) & 1) != 0;
-    const int nsx = tiles_1d(w, 128, stream_depth());
-    return (double)w >= 0.8 * 128.0 * nsx && (double)w * h >= 40000.0;
+    StreamPick sp{};
+    stream_strips(w, sp);
+    return (double)w >= 0.75 * 128.0 * sp.nsx && (double)w * h >= 40000.0;
 }
 
 // Pairs per chunk of a level: the iteration launches of a chunk re-read what the previous launch wrote, so a chunk
@@ -1244,7 +1252,9 @@ extern "C" int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out
         const TileCfg& c = kCfgs[tp.cfg];
         const int lp = (ws[s] + 3) / 4 * 4;
         if (level_streams(p, p->epsilon > 0.0f, s, ws[s], hs[s], va_align_up((size_t)lp * hs[s], 64))) {
-            const int plan[6] = {128, 0, stream_depth() > kStreamK1 ? 2 : 1, stream_depth(), tiles_1d(ws[s], 128, stream_depth()), 0};
+            StreamPick sp{};
+            stream_strips(ws[s], sp);
+            const int plan[6] = {128, 0, sp.two ? 2 : 1, sp.HX, sp.nsx, 0};
             memcpy(out + 6 * s, plan, sizeof(plan));
             continue;
         }
@@ -1397,7 +1407,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                 sa.taut = a.taut;
                 sa.theta = a.theta;
                 const dim3 grid(sp.nsx * sp.nch, nc);
-                const bool two = stream_depth() > kStreamK1;
+                const bool two = sp.two != 0;
                 for (int it = 0; it < p->iters;) {
                     const int rem = p->iters - it;
                     const bool w2 = two && rem > kStreamKH2;  // the two-wave kernel needs its last level in the second wave
