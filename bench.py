@@ -173,7 +173,7 @@ def main():
             busy_ms = prof["union_ms"] if prof["union_ms"] > 0 else prof["ms"]
             ach = alg_bytes / (busy_ms * 1e-3) / 1e9
             traffic = pmc_traffic_per_launch(args.block_iters, args.flow_streams)
-            roof = dict(bound="hbm", kernel="k_iter_tile (TV-L1 inner iterations)", achieved=ach, peak=HBM_PEAK_GBS,
+            roof = dict(bound="hbm", kernel="k_iter_stream + k_iter_tile (TV-L1 inner iterations)", achieved=ach, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic,
                         launches=int(prof["launches"]), avg_launch_us=prof["ms"] * 1e3 / prof["launches"],
                         alg_bytes_per_launch=alg_bytes / prof["launches"], kernel_ms_per_step=busy_ms / max(K, 1),

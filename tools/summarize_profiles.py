@@ -31,6 +31,8 @@ def main(prefix, out):
             n = r["Kernel_Name"]
             if "k_iter_tile" in n:
                 key = "k_iter_tile grid=%s" % r["Grid_Size"]
+            elif "k_iter_stream" in n:
+                key = "k_iter_stream grid=%s" % r["Grid_Size"]
             elif "conv3x3" in n:
                 key = "k_conv3x3_mfma"
             elif "k_warp" in n:
@@ -49,7 +51,7 @@ def main(prefix, out):
     f = sum(v["sum_KB"] for k, v in summ["FETCH_SIZE"].items() if k.startswith("k_iter"))
     w = sum(v["sum_KB"] for k, v in summ["WRITE_SIZE"].items() if k.startswith("k_iter"))
     n = sum(v["launches"] for k, v in summ["FETCH_SIZE"].items() if k.startswith("k_iter"))
-    print("k_iter_tile: FETCH raw %.1f GB, WRITE %.1f GB, %d launches; corrected %.3f GB/launch, %.1f GB/step"
+    print("k_iter_*: FETCH raw %.1f GB, WRITE %.1f GB, %d launches; corrected %.3f GB/launch, %.1f GB/step"
           % (f * 1024 / 1e9, w * 1024 / 1e9, n, (2 * f + w) * 1024 / n / 1e9, (2 * f + w) * 1024 / 1e9))
     rows = list(csv.DictReader(open(glob.glob(prefix + "_trace/*/*_kernel_trace.csv")[0])))
     agg = collections.defaultdict(list)
@@ -57,7 +59,7 @@ def main(prefix, out):
         n = r["Kernel_Name"]
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         g = "grid=%sx%s" % (r["Grid_Size_X"], r["Grid_Size_Y"])
-        for pat in ("k_iter_tile", "k_conv3x3_mfma", "k_warp", "k_fc_splitk", "k_fc_reduce", "k_nchw_to_nhwc_pad", "k_flow_to_stack"):
+        for pat in ("k_iter_tile", "k_iter_stream", "k_conv3x3_dma_f32", "k_conv3x3_mfma", "k_warp", "k_fc_splitk", "k_fc_reduce", "k_nchw_to_nhwc_pad", "k_flow_to_stack"):
             if pat in n:
                 tmpl = n[n.index(pat):].split("(")[0]
                 agg["%s %s" % (tmpl, g)].append(d)
