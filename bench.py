@@ -32,7 +32,7 @@ BATCH = 32
 
 
 def pmc_traffic_per_launch(block_iters, flow_streams):
-    """HBM bytes per k_iter_tile launch from the committed rocprofv3 PMC passes (profiles/rNN/
+    """HBM bytes per inner-iteration launch (k_iter_stream, k_iter_tile) from the committed rocprofv3 PMC passes (profiles/rNN/
     pmc_hbm_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command;
     FETCH_SIZE doubled per the gfx950 rule of MI355X_MICROARCH.md, verified on this kernel's known
     load count in profiles/README.md).  PMC cannot be collected inside a normal run: this reports the
@@ -165,7 +165,7 @@ def main():
         value = clips / elapsed
         roof = None
         if prof["launches"] > 0 and prof["ms"] > 0:
-            # `achieved`: algorithmic bytes of all k_iter_tile launches / wall time during which they run
+            # `achieved`: algorithmic bytes of all inner-iteration launches / wall time during which they run
             # (the union of the HIP-event intervals: with --flow-streams > 1 launches of different
             # streams overlap).  `avg_launch_us` is the plain per-launch average (sum of per-stream
             # kernel time / launches) that rocprofv3 --stats reports for the kernel.

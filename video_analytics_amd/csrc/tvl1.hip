@@ -15,12 +15,19 @@
 //   state    2 x [pair][6 = u1,u2,p11,p12,p21,p22][h][pitch]   ping-pong (halo reads vs writes)
 //   ro       [pair][4 = I1wx, I1wy, rho_c, 1/|grad|^2][h][pitch]  per-warp constants
 //
-// Dominant kernel: k_iter_tile.  One workgroup owns a (64*R) x (NW*C) pixel tile; every thread
-// keeps an R x C patch of all 10 fields in REGISTERS for `K` consecutive inner iterations
-// (temporal blocking with a K-pixel overlapped halo).  Horizontal neighbours come from the
-// adjacent lane by DPP wave shifts, vertical neighbours of the patch's first/last row from the
-// adjacent wave through a 2-row LDS exchange.  HBM traffic per pixel-iteration falls from the
-// algorithmic 64 B to about 64 B / K / tile_efficiency.
+// Dominant kernels: the inner iterations (S6), in two forms that share their arithmetic operation
+// for operation (and so their results, bit for bit):
+//   k_iter_tile    One workgroup owns a (64*R) x (NW*C) pixel tile; every thread keeps an R x C
+//                  patch of all 10 fields in REGISTERS for `K` consecutive inner iterations
+//                  (temporal blocking with a K-pixel overlapped halo).  Horizontal neighbours come
+//                  from the adjacent lane by DPP wave shifts, vertical neighbours of the patch's
+//                  first/last row from the adjacent wave through a 2-row LDS exchange.
+//   k_iter_stream  One wave (or a pipeline of two) owns a strip of 128 columns and streams its rows
+//                  top to bottom ONCE per launch, carrying every row through K iterations on the way
+//                  (time-skewed: level t works one row behind level t-1); no y halo, no barrier in
+//                  the one-wave form.  Used where the strips are well filled (level_streams()).
+// Either way the HBM traffic per pixel-iteration falls from the algorithmic 64 B to about
+// 64 B / K / efficiency.
 #include "va_internal.h"
 #include <cmath>
 #include <algorithm>
