@@ -64,11 +64,13 @@ def test_every_register_tile_candidate_bit_exact(oracle_tvl1, bit):
     assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 
-@pytest.mark.parametrize("H,W,nch", [(48, 64, 0), (100, 64, 3), (64, 300, 1), (150, 300, 3), (224, 224, 0), (57, 131, 1), (301, 259, 4)])
+@pytest.mark.parametrize("H,W,nch", [(48, 64, 0), (100, 64, 3), (64, 300, 1), (150, 300, 3), (224, 224, 0), (57, 131, 1), (301, 259, 4),
+                                     (16, 16, 0), (17, 19, 0), (33, 130, 1), (40, 700, 1), (129, 225, 2)])
 def test_streaming_kernel_bit_exact(oracle_tvl1, monkeypatch, H, W, nch):
     # tile_mask bit 8 forces k_iter_stream (the time-skewed row pipeline) on every level: one strip / several strips
     # with x halos, one chunk / several chunks of rows (VA_STREAM_NCH), iteration counts that are and are not a
-    # multiple of the pipeline depth (10), ragged widths with pitch padding
+    # multiple of the pipeline depth (16 with two waves, 10 with one), ragged widths with pitch padding, the smallest frames,
+    # seven strips (700 columns), 225 columns (one more than the two-wave form takes: one-wave strips with interior halos)
     monkeypatch.setenv("VA_STREAM_NCH", str(nch))
     gray = _frames(1, 3, H, W, seed=H + W)
     for iters, warps, nscales in ((10, 1, 1), (23, 2, 3)):
