@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from video_analytics_amd import _ffi, flow as vflow
 
+if os.environ.get('VA_LIB_EXP'): _ffi.LIB_PATH = os.path.abspath(os.environ['VA_LIB_EXP'])  # timing experiments with another build
 torch.manual_seed(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 224
 fr = (torch.rand(320, 2, n, n, device="cuda") * 255).to(torch.uint8)
