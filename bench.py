@@ -102,6 +102,12 @@ def main():
     ap.add_argument("--no-flow", action="store_true", help="CNN only on precomputed flow volumes (not the headline metric)")
     args = ap.parse_args()
 
+    from video_analytics_amd import launch
+    if launch.needs_spawn(args.gpus):
+        # started bare (`python bench.py --gpus N`): start one fresh process per GPU BEFORE anything in this
+        # process touches the GPU, wait for them, pass rank 0's JSON line through (children inherit stdout).
+        sys.exit(launch.self_spawn(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+
     import torch
     from video_analytics_amd import dist as vdist
     from video_analytics_amd import flow as vflow
@@ -110,7 +116,7 @@ def main():
     rank, local_rank, world = vdist.init()
     if world != args.gpus:
         if rank == 0:
-            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run\n" % (args.gpus, world))
+            sys.stderr.write("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d\n" % (args.gpus, world))
         sys.exit(2)
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible; the hot path has no CPU fallback\n")
@@ -158,6 +164,7 @@ def main():
     prof = vflow.profile_read(reset=True, device=local_rank)
     vflow.profile_enable(False, local_rank)
     assert allscores.shape[0] == world * K * BATCH
+    ranks_seen = vdist.ranks_seen()
     finite = bool(torch.isfinite(allscores).all().item())
 
     if rank == 0:
@@ -183,7 +190,7 @@ def main():
             cpu = cpu_baseline(args.cpu_clips, tv_kw)
         line = {
             "metric": "clips/sec (224x224, RGB+10-flow two-stream)",
-            "value": value, "unit": "clips/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "value": value, "unit": "clips/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed / max(K, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.cnn_dtype == "f32" else "bf16 (CNN) / f32 (TV-L1)", "data": "synthetic",
             "config": {"workload": "two-stream 224x224, 10-frame TV-L1 flow stack (5 scales x 5 warps x 300 its, fixed), "

@@ -75,6 +75,11 @@ def gather_scores(local, n_items, world=None):
     return out[:n_items]
 
 
+def ranks_seen():
+    """World size as the process group itself reports it (1 without a group): what actually took part."""
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()
