@@ -34,7 +34,10 @@
  *     the library owns only va_ctx and the packed-weight handle.  No hidden allocation and
  *     no host synchronisation inside va_vgg16_forward / va_tvl1_flow / va_flow_to_stack:
  *     all work is enqueued on `stream` (a hipStream_t; NULL = the null stream).
- *   - a handle may be used by one thread at a time; one process per GPU.
+ *   - a handle may be used by one thread at a time; one process per GPU.  Every entry point selects its
+ *     context's device itself (hipSetDevice); `stream` and all pointers must belong to that device.
+ *   - the library reads NO environment variable and keeps no process-global switch: every tuning or test
+ *     knob is a field of va_tvl1_params or a va_vgg16_set_option value of one handle.
  *   - there is NO CPU fallback in this library.
  */
 #ifndef VA_H
@@ -51,6 +54,7 @@ extern "C" {
 #define VA_ERR_INVALID 1   /* bad argument / shape: Python wrapper raises ValueError */
 #define VA_ERR_HIP 2       /* HIP runtime failure: RuntimeError */
 #define VA_ERR_WORKSPACE 3 /* workspace too small: ValueError */
+#define VA_ERR_STOPPED 4   /* a test switch cut the call short (VA_OPT_TRAIN_STOP_AT): RuntimeError in production code */
 
 #define VA_DTYPE_F32 0
 #define VA_DTYPE_BF16 1
@@ -83,6 +87,21 @@ int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_dim, int dtyp
                     void* stream, va_vgg16** out);
 void va_vgg16_destroy(va_vgg16* model);
 size_t va_vgg16_workspace_bytes(const va_vgg16* model, int batch);
+
+/*
+ * A/B and test switches of ONE model handle (defaults are the measured choices of DESIGN.md; results of the
+ * fp32 path do not depend on VA_OPT_F32_CONV_KERNEL, the three bf16 variants are bit-identical to each other):
+ *   VA_OPT_BF16_VARIANT     0 (default) tile and staging scheme chosen per layer; 1 = 64-channel tiles with one
+ *                           LDS buffer on every layer; 2 = the LDS-DMA ring on every layer
+ *   VA_OPT_F32_CONV_KERNEL  1 (default) LDS-DMA staged fp32 kernel where Cin % 32 == 0; 0 = register-staged kernel
+ *   VA_OPT_TRAIN_STOP_AT    -1 (default) full training step; i in [0,12]: va_vgg16_train_step returns
+ *                           VA_ERR_STOPPED after the backward pass of conv layer i, leaving the gradient buffers
+ *                           as that layer left them and the layers below WITHOUT their update (tests only)
+ */
+#define VA_OPT_BF16_VARIANT 1
+#define VA_OPT_F32_CONV_KERNEL 2
+#define VA_OPT_TRAIN_STOP_AT 3
+int va_vgg16_set_option(va_vgg16* model, int option, int value);
 
 /*
  * x: f32 (x_is_u8 = 0) or u8 (x_is_u8 = 1) [batch][c_in][224][224] NCHW.
@@ -127,8 +146,8 @@ typedef struct va_tvl1_params {
     int fast_math;    /* 0 (default): the exact arithmetic contract of DESIGN.md (correctly rounded
                          sqrt and division): results bit-identical to the CPU oracle.
                          1: the two special functions of the dual update use the 1-ulp hardware
-                         v_sqrt_f32 / v_rcp_f32 (1.6x faster inner iterations; flow within ~1e-4 px
-                         of the exact mode, tested with a 1e-3 px tolerance). */
+                         v_sqrt_f32 / v_rcp_f32 (measured: 11 % more clips/s; flow within 7e-6 px on average
+                         of the exact mode, 99.9 % of the pixels within 1e-3 px). */
     int tile_mask;    /* tuning/testing: bit i allows register-tile candidate i of the inner-iteration
                          kernel (bits 0-3: 256x32, 128x64, 84x96, 64x128 pixels, one 8-wave workgroup
                          per CU; bits 4-7: 256x16, 128x32, 84x48, 64x64, two 4-wave workgroups per
@@ -136,6 +155,14 @@ typedef struct va_tvl1_params {
                          128-column strip row by row through 10 iterations per pass) instead of the
                          register tiles; fixed-iteration mode only.  0 (default) = library choice per
                          level.  Results do not depend on it. */
+    /* Explicit tuning / test switches of the row pipeline (k_iter_stream); the library reads no environment variable.
+       Results do not depend on any of them. */
+    int stream_levels; /* -1 (default): the library decides per level; otherwise a bit set: bit s = pyramid level s
+                          (0 = full resolution) iterates with the row pipeline, every other level on the register tiles */
+    int stream_waves;  /* 0 (default): two-wave pipeline (16 iterations per pass) where a level has at most two strips,
+                          one-wave (10 per pass) elsewhere; 1: one-wave pipeline everywhere */
+    int stream_chunks; /* 0 (default): rows cut into as many chunks as fill the GPU; n > 0: n chunks (capped at h/32) */
+    int stream_slots;  /* 0 (default): target number of strip x chunk x pair jobs per call (640 two-wave / 1024 one-wave) */
 } va_tvl1_params;
 
 void va_tvl1_default_params(va_tvl1_params* p);
@@ -145,8 +172,9 @@ int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* h
 
 /* The register tiling va_tvl1_flow will use, level by level (host logic; HOST array of >= 6*16 ints): per level
  * { tile width, tile height, waves per workgroup, block depth K, tiles in x, tiles in y }; a level that streams
- * reports { 128, 0 (rows stream through), 1, 10, strips in x, 0 (chunks of rows: chosen per call from the
- * number of pairs) }.  Returns the number of levels (0 on bad arguments). */
+ * reports { 128 (strip width), 0 (rows stream through), waves of the row pipeline (2 or 1), iterations per pass
+ * (16 with two waves, 10 with one), strips in x, 0 (chunks of rows: chosen per call from the number of pairs) }.
+ * Returns the number of levels (0 on bad arguments). */
 int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out);
 
 size_t va_tvl1_workspace_bytes(int w, int h, int n_seq, int frames_per_seq, const va_tvl1_params* p);
@@ -249,8 +277,8 @@ int va_vgg16_train_step(va_vgg16* model, const void* x, int x_is_u8, const void*
 /* Debugging aid of the tests: byte offsets inside the training workspace -- out[0..12] the 13 conv outputs,
  * out[13..25] the pooled maps (0 where a layer has no pool), out[26], out[27] the two gradient buffers,
  * out[28] the gradient at the classifier input, out[29] the NHWC input (HOST array of 30).  With the
- * environment variable VA_TRAIN_STOP_AT=i set, va_vgg16_train_step returns after the backward pass of conv
- * layer i, leaving the gradient buffers as that layer left them. */
+ * va_vgg16_set_option(model, VA_OPT_TRAIN_STOP_AT, i), va_vgg16_train_step stops after the backward pass of conv
+ * layer i (return code VA_ERR_STOPPED), leaving the gradient buffers as that layer left them. */
 int va_vgg16_train_plan(const va_vgg16* model, int batch, unsigned long long* out);
 int va_vgg16_export_state(va_vgg16* model, int which, void* const* conv_w, void* const* conv_b,
                           void* const* fc_w, void* const* fc_b, void* stream);

@@ -18,9 +18,13 @@ def _frames(n_seq, n_frames, H, W, seed):
     return gray
 
 
+# tuning fields of va_tvl1_params the oracle has no counterpart for (results must not depend on them)
+PRODUCT_ONLY = ("block_iters", "tile_mask", "stream_levels", "stream_waves", "stream_chunks", "stream_slots")
+
+
 def _run_both(oracle_tvl1, gray, **kw):
     from video_analytics_amd import flow as vflow
-    okw = {("lambda_" if k == "lambda" else k): v for k, v in kw.items() if k not in ("block_iters", "tile_mask")}
+    okw = {("lambda_" if k == "lambda" else k): v for k, v in kw.items() if k not in PRODUCT_ONLY}
     ref = oracle_tvl1.tvl1_flow(gray.numpy(), oracle_tvl1.default_params(**okw), nthreads=8)
     out = vflow.tvl1_flow(gray.cuda(), **kw)
     torch.cuda.synchronize()
@@ -66,29 +70,27 @@ def test_every_register_tile_candidate_bit_exact(oracle_tvl1, bit):
 
 @pytest.mark.parametrize("H,W,nch", [(48, 64, 0), (100, 64, 3), (64, 300, 1), (150, 300, 3), (224, 224, 0), (57, 131, 1), (301, 259, 4),
                                      (16, 16, 0), (17, 19, 0), (33, 130, 1), (40, 700, 1), (129, 225, 2)])
-def test_streaming_kernel_bit_exact(oracle_tvl1, monkeypatch, H, W, nch):
+def test_streaming_kernel_bit_exact(oracle_tvl1, H, W, nch):
     # tile_mask bit 8 forces k_iter_stream (the time-skewed row pipeline) on every level: one strip / several strips
-    # with x halos, one chunk / several chunks of rows (VA_STREAM_NCH), iteration counts that are and are not a
+    # with x halos, one chunk / several chunks of rows (va_tvl1_params.stream_chunks), iteration counts that are and are not a
     # multiple of the pipeline depth (16 with two waves, 10 with one), ragged widths with pitch padding, the smallest frames,
     # seven strips (700 columns), 225 columns (one more than the two-wave form takes: one-wave strips with interior halos)
-    monkeypatch.setenv("VA_STREAM_NCH", str(nch))
     gray = _frames(1, 3, H, W, seed=H + W)
     for iters, warps, nscales in ((10, 1, 1), (23, 2, 3)):
-        ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=warps, nscales=nscales, tile_mask=1 << 8)
+        ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=warps, nscales=nscales, tile_mask=1 << 8,
+                             stream_chunks=nch)
         assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 
-def test_streaming_kernel_fast_math_and_mixed_levels(oracle_tvl1, monkeypatch):
+def test_streaming_kernel_fast_math_and_mixed_levels(oracle_tvl1):
     # levels that stream (plain row order) next to levels on the register tiles (interleaved pixel order): the
-    # up-sampling between them converts; VA_STREAM picks the levels
+    # up-sampling between them converts; va_tvl1_params.stream_levels picks the levels
     gray = _frames(2, 2, 224, 224, seed=77)
     ref = oracle_tvl1.tvl1_flow(gray.numpy(), oracle_tvl1.default_params(epsilon=0.0, iters=25, warps=2, nscales=4), nthreads=8)
     from video_analytics_amd import flow as vflow
-    for bits in ("0", "5", "10", "15"):
-        monkeypatch.setenv("VA_STREAM", bits)
-        out = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=25, warps=2, nscales=4).cpu().numpy()
-        assert np.array_equal(out, ref), "VA_STREAM=%s: max abs diff %g" % (bits, np.abs(out - ref).max())
-    monkeypatch.delenv("VA_STREAM")
+    for bits in (0, 5, 10, 15):
+        out = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=25, warps=2, nscales=4, stream_levels=bits).cpu().numpy()
+        assert np.array_equal(out, ref), "stream_levels=%d: max abs diff %g" % (bits, np.abs(out - ref).max())
     exact = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=25, warps=2, nscales=4, tile_mask=1 << 8)
     fast = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=25, warps=2, nscales=4, tile_mask=1 << 8, fast_math=1)
     tiles = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=25, warps=2, nscales=4, tile_mask=0xFF, fast_math=1)

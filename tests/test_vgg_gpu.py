@@ -112,6 +112,27 @@ def test_batch_40_crosses_fc_row_tile(weights3):
     m.close()
 
 
+@pytest.mark.parametrize("c_in", [3, 20])
+def test_benchmark_batch_32_matches_oracle_on_every_row(weights3, c_in):
+    """BASELINE configs[1]'s batch (32 clips per GPU): every row of both streams against the torch-CPU oracle
+    (the tile/brick choice of the conv kernels and the FC row tiling depend on the batch)."""
+    from oracle import vgg_oracle
+    from video_analytics_amd import vgg
+    torch.set_num_threads(8)
+    w = {k: [t.clone() for t in v] for k, v in weights3.items()}
+    if c_in != 3:
+        w["conv_w"][0] = vgg_oracle.copy_first_layer(w["conv_w"][0], c_in)
+    x = _inputs(32, c_in, seed=40 + c_in)
+    feat_r, desc_r, log_r = vgg_oracle.forward(x, w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"])
+    m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256)
+    feat, desc, logits = m.forward(x.cuda(), want_feat=True)
+    assert float((feat.cpu() - feat_r).abs().max()) < TOL
+    assert float((desc.cpu() - desc_r).abs().max()) < TOL
+    assert float((logits.cpu() - log_r).abs().max()) < TOL
+    assert torch.equal(logits.cpu().argmax(1), log_r.argmax(1))
+    m.close()
+
+
 def test_bf16_stream_tracks_the_fp32_stream(weights3):
     """BASELINE config 5 (bf16 conv stack, fp32 accumulate/classifier): not a parity configuration -- the
     test states its deviation from the fp32 oracle: relative error of the class scores below 3e-2 of their
@@ -134,7 +155,7 @@ def test_bf16_stream_tracks_the_fp32_stream(weights3):
 
 
 @pytest.mark.parametrize("c_in,B", [(3, 5), (20, 3), (3, 33)])
-def test_bf16_stream_against_its_own_restatement_and_across_staging_schemes(weights3, c_in, B, monkeypatch):
+def test_bf16_stream_against_its_own_restatement_and_across_staging_schemes(weights3, c_in, B):
     """(1) The bf16 path against its restatement (bf16-rounded operands, fp32 accumulation,
     oracle.vgg_oracle.forward_bf16): two valid bf16 evaluations that differ only in the fp32 accumulation
     order decorrelate their bf16 rounding decisions layer by layer, so they agree to the bf16 noise level
@@ -150,9 +171,10 @@ def test_bf16_stream_against_its_own_restatement_and_across_staging_schemes(weig
     x = _inputs(B, c_in, seed=11 + c_in)
     feat_r, desc_r, log_r = vgg_oracle.forward_bf16(x, w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"])
     outs = []
-    for variant in ("0", "1", "2"):
-        monkeypatch.setenv("VA_BF16_VARIANT", variant)
+    from video_analytics_amd import _ffi
+    for variant in (0, 1, 2):
         m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256, dtype="bf16")
+        m.set_option(_ffi.VA_OPT_BF16_VARIANT, variant)
         feat, desc, logits = m.forward(x.cuda(), want_feat=True)
         feat2, _, logits2 = m.forward(x.cuda(), want_feat=True)
         assert torch.equal(feat, feat2) and torch.equal(logits, logits2)

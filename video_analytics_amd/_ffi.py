@@ -10,12 +10,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libva_hip.so")
 
-VA_OK, VA_ERR_INVALID, VA_ERR_HIP, VA_ERR_WORKSPACE = 0, 1, 2, 3
+VA_OK, VA_ERR_INVALID, VA_ERR_HIP, VA_ERR_WORKSPACE, VA_ERR_STOPPED = 0, 1, 2, 3, 4
+VA_OPT_BF16_VARIANT, VA_OPT_F32_CONV_KERNEL, VA_OPT_TRAIN_STOP_AT = 1, 2, 3
 
 # every symbol include/va.h declares (tests check that the library exports exactly these)
 EXPORTS = [
     "va_version", "va_last_error", "va_ctx_create", "va_ctx_destroy",
-    "va_vgg16_create", "va_vgg16_destroy", "va_vgg16_workspace_bytes", "va_vgg16_forward", "va_vgg16_classify",
+    "va_vgg16_create", "va_vgg16_destroy", "va_vgg16_workspace_bytes", "va_vgg16_set_option", "va_vgg16_forward", "va_vgg16_classify",
     "va_copy_first_layer", "va_validate_batch",
     "va_tvl1_default_params", "va_tvl1_pyramid_sizes", "va_tvl1_tile_plan", "va_tvl1_workspace_bytes", "va_tvl1_flow",
     "va_flow_to_stack", "va_selftest_exact_math", "va_tvl1_profile_enable", "va_tvl1_profile_read",
@@ -39,6 +40,10 @@ class Tvl1Params(ctypes.Structure):
         ("block_iters", ctypes.c_int),
         ("fast_math", ctypes.c_int),
         ("tile_mask", ctypes.c_int),
+        ("stream_levels", ctypes.c_int),
+        ("stream_waves", ctypes.c_int),
+        ("stream_chunks", ctypes.c_int),
+        ("stream_slots", ctypes.c_int),
     ]
 
 
@@ -77,6 +82,8 @@ def lib():
     L.va_vgg16_destroy.restype = None
     L.va_vgg16_workspace_bytes.argtypes = [vp, ci]
     L.va_vgg16_workspace_bytes.restype = sz
+    L.va_vgg16_set_option.argtypes = [vp, ci, ci]
+    L.va_vgg16_set_option.restype = ci
     L.va_vgg16_forward.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]
     L.va_vgg16_forward.restype = ci
     L.va_vgg16_classify.argtypes = [vp, vp, ci, vp, vp, vp, sz, vp]
@@ -167,9 +174,13 @@ def ctx(device=None):
     return _ctx[device]
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """The CURRENT stream of ``device`` (a tensor's device or index; default: the current device): every binding
+    passes the device of the tensors it hands over, so that a tensor on cuda:1 never travels with cuda:0's stream."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if isinstance(device, torch.Tensor):
+        device = device.device
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def ptr(t):

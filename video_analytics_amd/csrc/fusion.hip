@@ -71,6 +71,7 @@ extern "C" int va_meter_update(va_ctx* ctx, const void* desc, const void* slot, 
                                void* stream)
 {
     VA_CHECK_ARG(ctx != nullptr, "va_meter_update: ctx is NULL");
+    VA_USE_DEVICE(ctx);
     VA_CHECK_ARG(desc && slot && sums && counts, "va_meter_update: NULL pointer");
     VA_CHECK_ARG(batch >= 1 && dim >= 1 && n_slots >= 1, "va_meter_update: batch, dim, n_slots must be >= 1 (got %d, %d, %d)", batch, dim, n_slots);
     k_meter_update<<<va_cdiv(dim, 256), 256, 0, (hipStream_t)stream>>>((const float*)desc, (const int*)slot, batch, dim, (float*)sums,
@@ -82,6 +83,7 @@ extern "C" int va_meter_update(va_ctx* ctx, const void* desc, const void* slot, 
 extern "C" int va_meter_average(va_ctx* ctx, const void* sums, const void* counts, int n_slots, int dim, void* avg, void* stream)
 {
     VA_CHECK_ARG(ctx != nullptr, "va_meter_average: ctx is NULL");
+    VA_USE_DEVICE(ctx);
     VA_CHECK_ARG(sums && counts && avg, "va_meter_average: NULL pointer");
     VA_CHECK_ARG(dim >= 1 && n_slots >= 1, "va_meter_average: dim, n_slots must be >= 1 (got %d, %d)", dim, n_slots);
     const size_t n = (size_t)n_slots * dim;
@@ -94,6 +96,7 @@ extern "C" int va_linear_svm_predict(va_ctx* ctx, const void* x, int n, int dim,
                                      void* scores, void* pred, void* stream)
 {
     VA_CHECK_ARG(ctx != nullptr, "va_linear_svm_predict: ctx is NULL");
+    VA_USE_DEVICE(ctx);
     VA_CHECK_ARG(x && coef && intercept && scores && pred, "va_linear_svm_predict: NULL pointer");
     VA_CHECK_ARG(n >= 1 && dim >= 1 && dim <= 8192 && n_class_rows >= 1,
                  "va_linear_svm_predict: need n >= 1, 1 <= dim <= 8192, n_class_rows >= 1 (got %d, %d, %d)", n, dim, n_class_rows);

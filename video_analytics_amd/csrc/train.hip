@@ -110,10 +110,13 @@ __global__ void k_ce_fwd_bwd(const float* __restrict__ logits, const long long* 
             if (l[c] > mx) { mx = l[c]; am = c; }
         float se = 0.0f;
         for (int c = 0; c < C; ++c) se += expf(l[c] - mx);
+        // label outside [0, C): no out-of-bounds read; loss and this row's gradient become NaN (nn.CrossEntropyLoss
+        // refuses such a target; the Python wrapper raises ValueError first when the labels are on the host)
         const long long y = labels[b];
-        loss += (logf(se) + mx) - l[y];
-        corr += (am == (int)y);
-        const float inv = 1.0f / se;
+        const bool yok = y >= 0 && y < (long long)C;
+        loss += yok ? (logf(se) + mx) - l[yok ? y : 0] : __builtin_nanf("");
+        corr += (yok && am == (int)y);
+        const float inv = yok ? 1.0f / se : __builtin_nanf("");
         for (int c = 0; c < C; ++c) dlogits[(size_t)b * C + c] = (expf(l[c] - mx) * inv - (c == (int)y ? 1.0f : 0.0f)) * invB;
     }
     sloss[threadIdx.x] = loss;
@@ -564,6 +567,7 @@ int fc_backward_dispatch(int B, F&& f)
 extern "C" int va_vgg16_train_init(va_vgg16* m, void* stream)
 {
     VA_CHECK_ARG(m != nullptr, "va_vgg16_train_init: model is NULL");
+    VA_USE_DEVICE(m->ctx);
     VA_CHECK_ARG(m->dtype == VA_DTYPE_F32, "va_vgg16_train_init: training is fp32 only");
     hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < 13; ++i) {
@@ -597,6 +601,7 @@ extern "C" int va_vgg16_train_step(va_vgg16* m, const void* x, int x_is_u8, cons
                                    void* stream)
 {
     VA_CHECK_ARG(m != nullptr && x != nullptr && labels != nullptr && loss_out != nullptr, "va_vgg16_train_step: NULL argument");
+    VA_USE_DEVICE(m->ctx);
     VA_CHECK_ARG(m->dtype == VA_DTYPE_F32, "va_vgg16_train_step: training is fp32 only");
     VA_CHECK_ARG(batch >= 1 && batch <= 64, "va_vgg16_train_step: batch %d out of range [1,64]", batch);
     VA_CHECK_ARG(m->conv[0].mom_w != nullptr && m->zeros_f32 != nullptr, "va_vgg16_train_step: call va_vgg16_train_init first");
@@ -617,7 +622,7 @@ extern "C" int va_vgg16_train_step(va_vgg16* m, const void* x, int x_is_u8, cons
     const float* in = F(T.x0);
     for (int i = 0; i < 13; ++i) {
         const ConvLayer& L = m->conv[i];
-        if (int rc = va_conv3x3_f32(L.hw, L.cin_pad, L.cout, L.wp, L.bias, in, F(T.y[i]), nullptr, 0, 0, B, m->zeros_f32, st)) return rc;
+        if (int rc = va_conv3x3_f32(L.hw, L.cin_pad, L.cout, L.wp, L.bias, in, F(T.y[i]), nullptr, 0, 0, B, m->zeros_f32, m->f32_conv, st)) return rc;
         in = F(T.y[i]);
         if (L.pool) {
             const size_t n = (size_t)B * (L.hw / 2) * (L.hw / 2) * (L.cout / 4);
@@ -664,8 +669,7 @@ extern "C" int va_vgg16_train_step(va_vgg16* m, const void* x, int x_is_u8, cons
     VA_LAUNCH_CHECK();
 
     // ---------------- feature stack backward + update ----------------
-    const char* stop_env = getenv("VA_TRAIN_STOP_AT");
-    const int stop_at = stop_env ? atoi(stop_env) : -1;
+    const int stop_at = m->train_stop_at;  // VA_OPT_TRAIN_STOP_AT (tests): -1 = the whole step
     const float* dout = F(T.da0);  // gradient at layer 12's pooled output
     int cur = -1;                  // which of the two gradient buffers holds `dout` (-1: neither)
     for (int i = 12; i >= 0; --i) {
@@ -686,7 +690,7 @@ extern "C" int va_vgg16_train_step(va_vgg16* m, const void* x, int x_is_u8, cons
             k_pack_dgrad_w<<<(unsigned)((nwt + 255) / 256), 256, 0, st>>>(L.wp, F(T.wt), L.cout, L.cin_pad, cin);
             float* g = F(T.g[1 - cur]);
             const float* mask = m->conv[i - 1].pool ? nullptr : F(T.y[i - 1]);
-            if (int rc = va_conv3x3_f32(L.hw, L.cout, cin, F(T.wt), m->zeros_f32, dyr, g, mask, 1, 0, B, m->zeros_f32, st)) return rc;
+            if (int rc = va_conv3x3_f32(L.hw, L.cout, cin, F(T.wt), m->zeros_f32, dyr, g, mask, 1, 0, B, m->zeros_f32, m->f32_conv, st)) return rc;
             dout = g;
         }
         // weight and bias gradients + update (dyr stays intact: the data gradient went to the other buffer)
@@ -714,7 +718,10 @@ extern "C" int va_vgg16_train_step(va_vgg16* m, const void* x, int x_is_u8, cons
         k_conv_bgrad_sgd<<<va_cdiv(L.cout, 64), 256, 0, st>>>(F(T.bpart), nblk, L.bias, L.mom_b, L.cout, lr, momentum);
         if (i > 0) cur = 1 - cur;
         VA_LAUNCH_CHECK();
-        if (stop_at == i) return VA_OK;  // debugging aid (VA_TRAIN_STOP_AT): leave the gradient buffers as layer i left them
+        if (stop_at == i) {  // debugging aid of the tests: leave the gradient buffers as layer i left them; NOT a completed step
+            va_set_error("va_vgg16_train_step: stopped after the backward pass of conv layer %d (VA_OPT_TRAIN_STOP_AT); layers below were not updated", i);
+            return VA_ERR_STOPPED;
+        }
     }
     return VA_OK;
 }
@@ -725,6 +732,7 @@ extern "C" int va_vgg16_export_state(va_vgg16* m, int which, void* const* conv_w
                                      void* const* fc_b, void* stream)
 {
     VA_CHECK_ARG(m != nullptr && conv_w && conv_b && fc_w && fc_b, "va_vgg16_export_state: NULL argument");
+    VA_USE_DEVICE(m->ctx);
     VA_CHECK_ARG(m->dtype == VA_DTYPE_F32, "va_vgg16_export_state: fp32 models only");
     VA_CHECK_ARG(which == 0 || (which == 1 && m->conv[0].mom_w), "va_vgg16_export_state: which must be 0, or 1 after va_vgg16_train_init");
     hipStream_t st = (hipStream_t)stream;
@@ -750,6 +758,7 @@ extern "C" int va_vgg16_import_state(va_vgg16* m, int which, const void* const* 
                                      const void* const* fc_w, const void* const* fc_b, void* stream)
 {
     VA_CHECK_ARG(m != nullptr && conv_w && conv_b && fc_w && fc_b, "va_vgg16_import_state: NULL argument");
+    VA_USE_DEVICE(m->ctx);
     VA_CHECK_ARG(m->dtype == VA_DTYPE_F32, "va_vgg16_import_state: fp32 models only");
     VA_CHECK_ARG(which == 0 || (which == 1 && m->conv[0].mom_w), "va_vgg16_import_state: which must be 0, or 1 after va_vgg16_train_init");
     hipStream_t st = (hipStream_t)stream;
@@ -775,6 +784,7 @@ extern "C" int va_vgg16_import_state(va_vgg16* m, int which, const void* const* 
 extern "C" int va_vgg16_train_plan(const va_vgg16* m, int batch, unsigned long long* out)
 {
     VA_CHECK_ARG(m != nullptr && out != nullptr && batch >= 1 && batch <= 64, "va_vgg16_train_plan: bad argument");
+    VA_USE_DEVICE(m->ctx);
     const TrainPlan T = plan_train(m, batch);
     for (int i = 0; i < 13; ++i) {
         out[i] = T.y[i];

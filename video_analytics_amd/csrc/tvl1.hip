@@ -1064,29 +1064,24 @@ constexpr int kStreamBit = 1 << 8;  // va_tvl1_params.tile_mask bit: iterate wit
 struct StreamPick {
     int nsx, nch, R, HX, two;
 };
-int stream_env(const char* name, int dflt)
-{
-    const char* e = getenv(name);
-    return e && *e ? atoi(e) : dflt;
-}
 // Strips of a level.  Two-wave pipeline (16 iterations per pass) where the deeper x halo costs nothing, i.e. where the
 // level has no interior strip (w <= 224); wider levels use the one-wave pipeline (10 per pass, halo 10: measured on
-// the 1280x720 pyramid).  VA_STREAM2=0 (experiment switch): one-wave everywhere.
-void stream_strips(int w, StreamPick& sp)
+// the 1280x720 pyramid).  va_tvl1_params.stream_waves = 1 (experiment switch): one-wave everywhere.
+void stream_strips(const va_tvl1_params* p, int w, StreamPick& sp)
 {
-    sp.two = stream_env("VA_STREAM2", 1) != 0 && tiles_1d(w, 128, 2 * kStreamKH2) <= 2;
+    sp.two = p->stream_waves != 1 && tiles_1d(w, 128, 2 * kStreamKH2) <= 2;
     sp.HX = sp.two ? 2 * kStreamKH2 : kStreamK1;  // even: strip origins stay 8-byte aligned
     sp.nsx = tiles_1d(w, 128, sp.HX);
 }
-StreamPick pick_stream(int w, int h, int npairs)
+StreamPick pick_stream(const va_tvl1_params* p, int w, int h, int npairs)
 {
     StreamPick sp{};
-    stream_strips(w, sp);
+    stream_strips(p, w, sp);
     // chunks of rows: the number of jobs (strip x chunk x pair) that keeps the GPU busiest was measured with one and
     // with two concurrent calls on different HIP streams: ~1024 one-wave jobs, ~640 two-wave jobs per call (256 CUs x
     // 8 waves); rows per chunk not below 32
-    const int slots = stream_env("VA_STREAM_SLOTS", sp.two ? 640 : 1024);
-    int nch = stream_env("VA_STREAM_NCH", 0);
+    const int slots = p->stream_slots > 0 ? p->stream_slots : (sp.two ? 640 : 1024);
+    int nch = p->stream_chunks;
     if (nch <= 0) nch = (int)((double)slots / ((double)npairs * sp.nsx) + 0.5);
     if (nch > h / 32) nch = h / 32;
     if (nch < 1) nch = 1;
@@ -1097,16 +1092,15 @@ StreamPick pick_stream(int w, int h, int npairs)
 // Level (w, h) of the pyramid iterates with k_iter_stream: wherever its 128-column strips are well filled and the level
 // is large enough for a GPU-full of strip x chunk jobs (measured, tools/bench_tvl1_levels.py: 224^2 and every level of
 // the 1280x720 pyramid win, 179^2 and below lose to the register tiles).  tile_mask bit 8 forces it (tests);
-// VA_STREAM=<bits> is an experiment switch (bit s = level s, 0 = never).
+// va_tvl1_params.stream_levels >= 0 is the explicit per-level choice (bit s = level s, 0 = never).
 bool level_streams(const va_tvl1_params* p, bool eps, int s, int w, int h, size_t plane)
 {
     if (eps || (double)plane * kNF_STATE * sizeof(float) >= 2147483648.0) return false;  // 32-bit buffer offsets
     if (p->tile_mask & kStreamBit) return true;
     if (p->tile_mask != 0) return false;
-    const int env = stream_env("VA_STREAM", -1);
-    if (env >= 0) return ((env >> s) & 1) != 0;
+    if (p->stream_levels >= 0) return ((p->stream_levels >> s) & 1) != 0;
     StreamPick sp{};
-    stream_strips(w, sp);
+    stream_strips(p, w, sp);
     return (double)w >= 0.75 * 128.0 * sp.nsx && (double)w * h >= 40000.0;
 }
 
@@ -1158,6 +1152,9 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
     VA_CHECK_ARG(p->block_iters >= 0 && p->block_iters <= 64, "va_tvl1: block_iters must be in [0,64]");
     VA_CHECK_ARG(p->fast_math == 0 || p->fast_math == 1, "va_tvl1: fast_math must be 0 or 1");
     VA_CHECK_ARG(p->tile_mask >= 0 && p->tile_mask < (1 << (kNumCfgs + 1)), "va_tvl1: tile_mask must be in [0, %d]", (1 << (kNumCfgs + 1)) - 1);
+    VA_CHECK_ARG(p->stream_levels >= -1 && p->stream_levels < (1 << kMaxScales) && (p->stream_waves == 0 || p->stream_waves == 1) &&
+                     p->stream_chunks >= 0 && p->stream_slots >= 0,
+                 "va_tvl1: stream_levels must be -1 or a level bit set, stream_waves 0 or 1, stream_chunks and stream_slots >= 0");
     VA_CHECK_ARG(p->tau / p->theta <= 1000.0f && p->lambda * p->theta <= 1000.0f, "va_tvl1: tau/theta and lambda*theta must be <= 1000");
     return VA_OK;
 }
@@ -1236,6 +1233,10 @@ extern "C" void va_tvl1_default_params(va_tvl1_params* p)
     p->block_iters = 0;
     p->fast_math = 0;
     p->tile_mask = 0;
+    p->stream_levels = -1;
+    p->stream_waves = 0;
+    p->stream_chunks = 0;
+    p->stream_slots = 0;
 }
 
 extern "C" int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* hs)
@@ -1260,7 +1261,7 @@ extern "C" int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out
         const int lp = (ws[s] + 3) / 4 * 4;
         if (level_streams(p, p->epsilon > 0.0f, s, ws[s], hs[s], va_align_up((size_t)lp * hs[s], 64))) {
             StreamPick sp{};
-            stream_strips(ws[s], sp);
+            stream_strips(p, ws[s], sp);
             const int plan[6] = {128, 0, sp.two ? 2 : 1, sp.HX, sp.nsx, 0};
             memcpy(out + 6 * s, plan, sizeof(plan));
             continue;
@@ -1288,6 +1289,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                             void* stream)
 {
     VA_CHECK_ARG(ctx != nullptr, "va_tvl1_flow: ctx is NULL");
+    VA_USE_DEVICE(ctx);
     VA_CHECK_ARG(frames != nullptr && flow != nullptr && workspace != nullptr, "va_tvl1_flow: NULL buffer");
     if (int rc = check_params(p, w, h, n_seq, frames_per_seq)) return rc;
     VA_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "va_tvl1_flow: workspace must be 256-byte aligned");
@@ -1398,7 +1400,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
             a.pair0 = c0;
             int launches = 0;
             if (strm) {
-                const StreamPick sp = pick_stream(lw, lh, nc);
+                const StreamPick sp = pick_stream(p, lw, lh, nc);
                 StreamArgs sa{};
                 sa.ro = ro;
                 sa.plane = plane;
@@ -1492,6 +1494,7 @@ extern "C" int va_flow_to_stack(va_ctx* ctx, const void* flow, int n_pairs, int 
                                 float stdv, void* stack, void* stream)
 {
     VA_CHECK_ARG(ctx != nullptr, "va_flow_to_stack: ctx is NULL");
+    VA_USE_DEVICE(ctx);
     VA_CHECK_ARG(flow != nullptr && stack != nullptr, "va_flow_to_stack: NULL buffer");
     VA_CHECK_ARG(n_pairs >= 1 && w >= 1 && h >= 1, "va_flow_to_stack: bad shape");
     VA_CHECK_ARG(bound > 0.0f && stdv > 0.0f, "va_flow_to_stack: bound and std must be > 0");
@@ -1504,6 +1507,7 @@ extern "C" int va_flow_to_stack(va_ctx* ctx, const void* flow, int n_pairs, int 
 extern "C" int va_selftest_exact_math(va_ctx* ctx, float lo, float hi, unsigned long long* mismatches, void* stream)
 {
     VA_CHECK_ARG(ctx != nullptr && mismatches != nullptr, "va_selftest_exact_math: NULL argument");
+    VA_USE_DEVICE(ctx);
     VA_CHECK_ARG(lo >= kSqrtReg && hi <= 1e30f && lo <= hi, "va_selftest_exact_math: range must lie in [2^-100, 1e30]");
     unsigned ulo, uhi;
     memcpy(&ulo, &lo, 4);
@@ -1517,6 +1521,7 @@ extern "C" int va_selftest_exact_math(va_ctx* ctx, float lo, float hi, unsigned 
 extern "C" int va_tvl1_profile_enable(va_ctx* ctx, int on)
 {
     VA_CHECK_ARG(ctx != nullptr, "va_tvl1_profile_enable: ctx is NULL");
+    VA_USE_DEVICE(ctx);
     ctx->prof_on = on != 0;
     if (on) {
         // time origin: everything recorded later (on any stream) is measured against it
@@ -1531,6 +1536,7 @@ extern "C" int va_tvl1_profile_enable(va_ctx* ctx, int on)
 extern "C" int va_tvl1_profile_read(va_ctx* ctx, double* out, int reset)
 {
     VA_CHECK_ARG(ctx != nullptr && out != nullptr, "va_tvl1_profile_read: NULL argument");
+    VA_USE_DEVICE(ctx);
     std::vector<std::pair<float, float>> iv;
     for (va_prof_span& s : ctx->prof_spans) {
         VA_HIP(hipEventSynchronize(s.end));

@@ -42,5 +42,9 @@ void va_set_error(const char* fmt, ...);
 
 #define VA_LAUNCH_CHECK() VA_HIP(hipGetLastError())
 
+// Every entry point runs on its context's device whatever the calling thread's current device is (launches,
+// events and allocations follow hipSetDevice; the caller's stream and pointers must belong to that device).
+#define VA_USE_DEVICE(ctx_) VA_HIP(hipSetDevice((ctx_)->device))
+
 static inline size_t va_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int va_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -906,9 +906,12 @@ __global__ void k_validate_batch(const float* __restrict__ logits, const long lo
             if (l[c] > mx) { mx = l[c]; am = c; }
         float se = 0.0f;
         for (int c = 0; c < C; ++c) se += expf(l[c] - mx);
+        // A label outside [0, C) (nn.CrossEntropyLoss refuses it: "Target y is out of bounds") reads nothing and makes
+        // the batch loss NaN; the Python wrapper raises ValueError before the call when the labels are on the host.
         const long long y = labels[b];
-        loss += (logf(se) + mx) - l[y];
-        corr += (am == (int)y);
+        const bool yok = y >= 0 && y < (long long)C;
+        loss += yok ? (logf(se) + mx) - l[yok ? y : 0] : __builtin_nanf("");
+        corr += (yok && am == (int)y);
     }
     sloss[threadIdx.x] = loss;
     scorr[threadIdx.x] = corr;
@@ -936,7 +939,7 @@ constexpr long VA_WIDE_MIN = 512;           // register-staged fp32 kernel: 128-
 constexpr int VA_RING = 3;                  // depth of the LDS-DMA ring (two workgroups per CU)
 constexpr long VA_RING_MAXGRID = 1024;      // bf16: ring + 64-channel tiles below this many workgroups (the 14x14 layers)
 constexpr long VA_RING_MAXGRID_F32 = 1024;  // fp32: the same threshold (0 and 4096 measured 2-4 % slower)
-constexpr int VA_F32_CONV_DEFAULT = 1;      // 1: LDS-DMA fp32 kernel where Cin % 32 == 0; VA_F32_CONV=0 selects the register-staged one (A/B)
+constexpr int VA_F32_CONV_DEFAULT = 1;      // 1: LDS-DMA fp32 kernel where Cin % 32 == 0; va_vgg16_set_option(VA_OPT_F32_CONV_KERNEL, 0) selects the register-staged one (A/B)
 constexpr int VA_CIN_ALIGN = 16;            // fp32 first-layer channel padding (3 -> 16: register-staged kernel; 20 -> 32: DMA kernel)
 
 void pick_brick(int W, int H, int B, int& lgTW, int& lgTH, int& TB)
@@ -959,7 +962,7 @@ void pick_brick(int W, int H, int B, int& lgTW, int& lgTH, int& TB)
 }
 
 int launch_conv_ex(int hw, int cin_pad, int cout, const float* wp, const float* bias, const float* in, float* out,
-                   const float* mask, int linear, bool pool, int B, const float* zeros, hipStream_t st)
+                   const float* mask, int linear, bool pool, int B, const float* zeros, int f32_conv, hipStream_t st)
 {
     ConvArgs a{};
     a.in = in;
@@ -977,10 +980,6 @@ int launch_conv_ex(int hw, int cin_pad, int cout, const float* wp, const float* 
     a.tiles_x = va_cdiv(hw, 1 << a.lgTW);
     a.tiles_y = va_cdiv(hw, 1 << a.lgTH);
     const int tiles_b = va_cdiv(B, a.TB);
-    static const int f32_conv = [] {
-        const char* e = getenv("VA_F32_CONV");  // A/B testing: 0 = register-staged kernel, 1 = LDS-DMA kernel
-        return e ? atoi(e) : VA_F32_CONV_DEFAULT;
-    }();
     if (f32_conv == 1 && zeros != nullptr && cin_pad % kDmaBK == 0) {
         const long grid64 = (long)(cout / 64) * a.tiles_x * a.tiles_y * tiles_b;
         const int ksteps = 9 * (cin_pad / kDmaBK);
@@ -1019,9 +1018,9 @@ int launch_conv_ex(int hw, int cin_pad, int cout, const float* wp, const float* 
     return VA_OK;
 }
 
-int launch_conv(const ConvLayer& L, const float* zeros, const float* in, float* out, int B, hipStream_t st)
+int launch_conv(const ConvLayer& L, const float* zeros, const float* in, float* out, int B, int f32_conv, hipStream_t st)
 {
-    return launch_conv_ex(L.hw, L.cin_pad, L.cout, L.wp, L.bias, in, out, nullptr, 0, L.pool, B, zeros, st);
+    return launch_conv_ex(L.hw, L.cin_pad, L.cout, L.wp, L.bias, in, out, nullptr, 0, L.pool, B, zeros, f32_conv, st);
 }
 
 int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const __bf16* in, void* out, bool out_f32, int B, hipStream_t st)
@@ -1136,9 +1135,9 @@ WsPlan plan_ws(const va_vgg16* m, int B)
 }  // namespace
 
 int va_conv3x3_f32(int hw, int cin_pad, int cout, const float* wp, const float* bias, const float* in, float* out,
-                   const float* mask, int linear, int pool, int B, const float* zeros, hipStream_t st)
+                   const float* mask, int linear, int pool, int B, const float* zeros, int f32_conv, hipStream_t st)
 {
-    return launch_conv_ex(hw, cin_pad, cout, wp, bias, in, out, mask, linear, pool != 0, B, zeros, st);
+    return launch_conv_ex(hw, cin_pad, cout, wp, bias, in, out, mask, linear, pool != 0, B, zeros, f32_conv, st);
 }
 
 int va_fc_f32(const float* A, const float* Wt, const float* bias, float* out, float* slab, int M, int N, int K, int relu, hipStream_t st)
@@ -1179,6 +1178,7 @@ extern "C" int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_di
                                va_vgg16** out)
 {
     VA_CHECK_ARG(ctx != nullptr && out != nullptr, "va_vgg16_create: NULL ctx/out");
+    VA_USE_DEVICE(ctx);
     *out = nullptr;
     VA_CHECK_ARG(c_in >= 1 && c_in <= 64, "va_vgg16_create: c_in %d out of range [1,64]", c_in);
     VA_CHECK_ARG(n_classes >= 1 && n_classes <= 4096 && desc_dim >= 16 && desc_dim <= 4096 && desc_dim % 16 == 0,
@@ -1203,7 +1203,9 @@ extern "C" int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_di
         va_set_error("va_vgg16_create: hipMalloc failed for the zero line");
         return fail(VA_ERR_HIP);
     }
-    if (const char* e = getenv("VA_BF16_VARIANT")) m->bf16_variant = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 0;  // tests only
+    m->bf16_variant = 0;
+    m->f32_conv = VA_F32_CONV_DEFAULT;
+    m->train_stop_at = -1;
     if (dtype == VA_DTYPE_BF16) {
         if (hipMalloc(&m->zeros, 256) != hipSuccess || hipMemsetAsync(m->zeros, 0, 256, st) != hipSuccess) {
             va_set_error("va_vgg16_create: hipMalloc failed for the zero line");
@@ -1297,6 +1299,7 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
                                 void* workspace, size_t workspace_bytes, void* stream)
 {
     VA_CHECK_ARG(m != nullptr, "va_vgg16_forward: model is NULL");
+    VA_USE_DEVICE(m->ctx);
     VA_CHECK_ARG(x != nullptr && workspace != nullptr, "va_vgg16_forward: NULL input/workspace");
     VA_CHECK_ARG(batch >= 1 && batch <= 4096, "va_vgg16_forward: batch %d out of range [1,4096]", batch);
     VA_CHECK_ARG(!x_is_u8 || (m->in_mean && m->in_std), "va_vgg16_forward: u8 input needs in_mean/in_std at create time");
@@ -1337,7 +1340,7 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
             k_nchw_to_nhwc_pad<float, float><<<pgrid, 256, 0, st>>>((const float*)x, act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
         VA_LAUNCH_CHECK();
         for (int i = 0; i < 13; ++i) {
-            if (int rc = launch_conv(m->conv[i], m->zeros_f32, act[cur], act[cur ^ 1], B, st)) return rc;
+            if (int rc = launch_conv(m->conv[i], m->zeros_f32, act[cur], act[cur ^ 1], B, m->f32_conv, st)) return rc;
             cur ^= 1;
         }
     }
@@ -1351,10 +1354,33 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
     return VA_OK;
 }
 
+extern "C" int va_vgg16_set_option(va_vgg16* m, int option, int value)
+{
+    VA_CHECK_ARG(m != nullptr, "va_vgg16_set_option: model is NULL");
+    switch (option) {
+        case VA_OPT_BF16_VARIANT:
+            VA_CHECK_ARG(value >= 0 && value <= 2, "va_vgg16_set_option: VA_OPT_BF16_VARIANT must be 0, 1 or 2");
+            m->bf16_variant = value;
+            return VA_OK;
+        case VA_OPT_F32_CONV_KERNEL:
+            VA_CHECK_ARG(value == 0 || value == 1, "va_vgg16_set_option: VA_OPT_F32_CONV_KERNEL must be 0 or 1");
+            m->f32_conv = value;
+            return VA_OK;
+        case VA_OPT_TRAIN_STOP_AT:
+            VA_CHECK_ARG(value >= -1 && value <= 12, "va_vgg16_set_option: VA_OPT_TRAIN_STOP_AT must be in [-1,12]");
+            m->train_stop_at = value;
+            return VA_OK;
+        default:
+            va_set_error("va_vgg16_set_option: unknown option %d", option);
+            return VA_ERR_INVALID;
+    }
+}
+
 extern "C" int va_vgg16_classify(va_vgg16* m, const void* feat, int batch, void* desc, void* logits, void* workspace,
                                  size_t workspace_bytes, void* stream)
 {
     VA_CHECK_ARG(m != nullptr, "va_vgg16_classify: model is NULL");
+    VA_USE_DEVICE(m->ctx);
     VA_CHECK_ARG(feat != nullptr && workspace != nullptr, "va_vgg16_classify: NULL input/workspace");
     VA_CHECK_ARG(batch >= 1 && batch <= 4096, "va_vgg16_classify: batch %d out of range [1,4096]", batch);
     VA_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "va_vgg16_classify: workspace must be 256-byte aligned");
@@ -1378,6 +1404,7 @@ extern "C" int va_vgg16_classify(va_vgg16* m, const void* feat, int batch, void*
 extern "C" int va_copy_first_layer(va_ctx* ctx, const void* w_rgb, int cout, int n_in, void* w_out, void* stream)
 {
     VA_CHECK_ARG(ctx != nullptr && w_rgb != nullptr && w_out != nullptr, "va_copy_first_layer: NULL argument");
+    VA_USE_DEVICE(ctx);
     VA_CHECK_ARG(cout >= 1 && n_in >= 1 && (long)cout * n_in * 9 < (1L << 30), "va_copy_first_layer: bad shape");
     const int n = cout * n_in * 9;
     k_copy_first_layer<<<va_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>((const float*)w_rgb, (float*)w_out, cout, n_in);
@@ -1389,6 +1416,7 @@ extern "C" int va_validate_batch(va_ctx* ctx, const void* logits, const void* la
                                  void* stream)
 {
     VA_CHECK_ARG(ctx != nullptr && logits != nullptr && labels != nullptr && out != nullptr, "va_validate_batch: NULL argument");
+    VA_USE_DEVICE(ctx);
     VA_CHECK_ARG(batch >= 1 && n_classes >= 1, "va_validate_batch: bad shape");
     k_validate_batch<<<1, 256, 0, (hipStream_t)stream>>>((const float*)logits, (const long long*)labels, batch, n_classes, (float*)out);
     VA_LAUNCH_CHECK();

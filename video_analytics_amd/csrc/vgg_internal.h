@@ -27,7 +27,10 @@ struct va_vgg16 {
     float* fc_mom_w[4];  // momentum buffers of the classifier (training)
     float* fc_mom_b[4];
     float* zeros_f32;    // >= 512 zero floats (training: bias of the linear dgrad convolutions)
-    int bf16_variant;  // testing: 0 = automatic tile/staging choice, 1 = 64-channel tiles + single buffer, 2 = DMA ring everywhere
+    // va_vgg16_set_option (explicit A/B and test switches; nothing is read from the environment)
+    int bf16_variant;   // VA_OPT_BF16_VARIANT: 0 = automatic tile/staging choice, 1 = 64-channel tiles + single buffer, 2 = DMA ring everywhere
+    int f32_conv;       // VA_OPT_F32_CONV_KERNEL: 1 = LDS-DMA kernel where Cin % 32 == 0 (default), 0 = register-staged kernel
+    int train_stop_at;  // VA_OPT_TRAIN_STOP_AT: -1 = full step; i = va_vgg16_train_step returns VA_ERR_STOPPED after conv layer i's backward
 };
 
 
@@ -35,7 +38,7 @@ struct va_vgg16 {
 // out = conv(in) + bias, then ReLU unless `linear`, then zeroed where mask[same index] <= 0 (mask may be NULL;
 // only without pooling), then 2x2 max-pooled when `pool`.  zeros: the model's zeros_f32 (>= 512 zero floats).
 int va_conv3x3_f32(int hw, int cin_pad, int cout, const float* wp, const float* bias, const float* in, float* out,
-                   const float* mask, int linear, int pool, int B, const float* zeros, hipStream_t st);
+                   const float* mask, int linear, int pool, int B, const float* zeros, int f32_conv, hipStream_t st);
 // out[M][N] = A[M][K] . Wt[N][K]^T + bias (+ReLU); slab: >= va_fc_slab_floats(M, N, K) floats of scratch
 int va_fc_f32(const float* A, const float* Wt, const float* bias, float* out, float* slab, int M, int N, int K, int relu, hipStream_t st);
 size_t va_fc_slab_floats(int M, int N, int K);

@@ -62,7 +62,7 @@ def tvl1_flow(frames, params=None, ws_slot=0, out=None, **over):
                 or not flow.is_contiguous()):
             raise ValueError("tvl1_flow: out must be a contiguous float32 [%d,2,%d,%d] tensor on the frames' device" % (S * (F - 1), H, W))
     _ffi.check(L.va_tvl1_flow(c, _ffi.ptr(frames), int(frames.dtype == torch.uint8), S, F, W, H, ctypes.byref(p),
-                              _ffi.ptr(flow), _ffi.ptr(ws), ws.numel(), _ffi.stream_ptr()))
+                              _ffi.ptr(flow), _ffi.ptr(ws), ws.numel(), _ffi.stream_ptr(frames.device)))
     return flow
 
 
@@ -113,7 +113,7 @@ def flow_to_stack(flow, bound=FLOW_BOUND, mean=NORM_MEANS_TF[0], std=NORM_STDS_T
     N, _, H, W = flow.shape
     out = torch.empty((2 * N, H, W), dtype=torch.float32, device=flow.device)
     _ffi.check(_ffi.lib().va_flow_to_stack(_ffi.ctx(flow.device.index), _ffi.ptr(flow), N, W, H, float(bound),
-                                           float(mean), float(std), _ffi.ptr(out), _ffi.stream_ptr()))
+                                           float(mean), float(std), _ffi.ptr(out), _ffi.stream_ptr(flow.device)))
     return out
 
 

@@ -47,6 +47,8 @@ class DescriptorMeters(object):
     def update(self, desc, names, labels):
         if not isinstance(desc, torch.Tensor) or not desc.is_cuda or desc.dtype != torch.float32:
             raise ValueError("DescriptorMeters.update: desc must be a CUDA float32 tensor")
+        if desc.device != self.device:
+            raise ValueError("DescriptorMeters.update: desc is on %s, the meters on %s" % (desc.device, self.device))
         if desc.dim() != 2 or desc.shape[1] != self.dim or desc.shape[0] != len(names):
             raise ValueError("DescriptorMeters.update: desc must be [len(names), %d]" % self.dim)
         idx = []
@@ -61,7 +63,7 @@ class DescriptorMeters(object):
         slot = torch.tensor(idx, dtype=torch.int32).to(self.device, non_blocking=True)
         desc = desc.contiguous()
         _ffi.check(_ffi.lib().va_meter_update(_ffi.ctx(self.device.index), _ffi.ptr(desc), _ffi.ptr(slot), desc.shape[0], self.dim,
-                                              _ffi.ptr(self.sums), _ffi.ptr(self.counts), self.sums.shape[0], _ffi.stream_ptr()))
+                                              _ffi.ptr(self.sums), _ffi.ptr(self.counts), self.sums.shape[0], _ffi.stream_ptr(self.device)))
 
     def average(self):
         """-> float32 [n_videos, dim] on the device (AverageMeter.avg of every video, first-seen order)."""
@@ -69,7 +71,7 @@ class DescriptorMeters(object):
         avg = torch.empty((max(n, 1), self.dim), dtype=torch.float32, device=self.device)
         if n:
             _ffi.check(_ffi.lib().va_meter_average(_ffi.ctx(self.device.index), _ffi.ptr(self.sums), _ffi.ptr(self.counts), n, self.dim,
-                                                   _ffi.ptr(avg), _ffi.stream_ptr()))
+                                                   _ffi.ptr(avg), _ffi.stream_ptr(self.device)))
         return avg[:n]
 
     def as_dict(self):
@@ -103,6 +105,6 @@ def linear_svm_predict(descriptors, coef, intercept, classes, device=None, retur
     pred = torch.empty((n,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         _ffi.check(_ffi.lib().va_linear_svm_predict(_ffi.ctx(dev.index), _ffi.ptr(x), n, x.shape[1], _ffi.ptr(w), _ffi.ptr(b), c,
-                                                    _ffi.ptr(scores), _ffi.ptr(pred), _ffi.stream_ptr()))
+                                                    _ffi.ptr(scores), _ffi.ptr(pred), _ffi.stream_ptr(dev)))
     out = classes[pred.cpu().numpy()]
     return (out, scores.cpu().numpy()) if return_scores else out

@@ -233,3 +233,25 @@ class SpatialNetwork(object):
             saveVideoDescriptors(self.trainDict, self.TRAIN_CSV, self.gpu)
             saveVideoDescriptors(self.testDict, self.TEST_CSV, self.gpu)
         return precision, loss
+
+
+def main(weights=None):
+    """The spatial-stream script (Sheet03/spatialModel.py:286-298): optional frame extraction, the train and test
+    datasets over the frame directories of ``parameters.py`` (the SAME random transforms for test as for train), their
+    loaders, the network, ``execute()``.  ``weights``: see ``SpatialNetwork`` (the reference downloads ImageNet weights)."""
+    from . import parameters as P
+    from .utils import convertVideosToFrames, getDataLoader, getTransforms
+    if P.CONVERT:
+        convertVideosToFrames(P.DATA_DIR, P.FRAMES_DIR_TEST, P.VIDEOLIST_TEST, mode="test")
+    tf = getTransforms()
+    trainSet = SpatialDataset(P.VIDEOLIST_TRAIN, P.FRAMES_DIR_TRAIN, tf, frameSampleSize=2, actionLabelLoc=P.ACTIONLABEL_FILE)
+    testSet = SpatialDataset(P.VIDEOLIST_TEST, P.FRAMES_DIR_TEST, tf, mode="test", actionLabelLoc=P.ACTIONLABEL_FILE)
+    net = SpatialNetwork(P.NACTION_CLASSES, P.NEPOCHS, P.INITIAL_LR, P.MOMENTUM_VAL, P.VIDEO_DESCRIPTOR_DIM,
+                         getDataLoader(trainSet, batchSize=P.SPATIAL_BATCH_SIZE),
+                         getDataLoader(testSet, batchSize=P.SPATIAL_BATCH_SIZE), P.MILESTONES_LR, P.CHECKPOINT_DIR,
+                         gpu=True, weights=weights)  # gpu=True is hard-coded in the reference as well (:297)
+    return net.execute()
+
+
+if __name__ == "__main__":
+    main()

@@ -97,3 +97,24 @@ class TemporalNetwork(SpatialNetwork):
 
     CKP_FILE, BEST_FILE = MOTION_CKP_FILE, MOTION_BEST_FILE
     TRAIN_CSV, TEST_CSV, PERFORMANCE_CSV = TEMPORAL_TRAIN_CSV_LOC, TEMPORAL_TEST_CSV_LOC, TEMPORAL_PERFORMANCE_LOC
+
+
+def main(weights=None):
+    """The motion-stream script (Sheet03/temporalModel.py:315-324): datasets over the flow-image directory, loaders,
+    network, ``execute()``."""
+    from . import parameters as P
+    from .utils import getDataLoader, getTransforms
+    tf = getTransforms()
+    L = P.VIDEO_INPUT_FLOW_COUNT
+    trainSet = TemporalDataset(P.VIDEOLIST_TRAIN, P.FLOW_DATA_DIR, tf, flowSampleSize=L, actionLabelLoc=P.ACTIONLABEL_FILE)
+    testSet = TemporalDataset(P.VIDEOLIST_TEST, P.FLOW_DATA_DIR, tf, flowSampleSize=L, mode="test",
+                              actionLabelLoc=P.ACTIONLABEL_FILE)
+    net = TemporalNetwork(P.NACTION_CLASSES, L, P.NEPOCHS, P.INITIAL_LR, P.MOMENTUM_VAL, P.VIDEO_DESCRIPTOR_DIM,
+                          getDataLoader(trainSet, batchSize=P.TEMPORAL_BATCH_SIZE),
+                          getDataLoader(testSet, batchSize=P.TEMPORAL_BATCH_SIZE), P.MILESTONES_LR, P.CHECKPOINT_DIR,
+                          gpu=True, weights=weights)
+    return net.execute()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,9 +4,10 @@ Pure-Python string/indexing logic is bit-exact with the reference lines cited pe
 The image transforms restate the torchvision ~0.2 classes the reference composes
 (``getTransforms``, Sheet03/utils.py:137-151) on numpy/torch, because torchvision is not part of this
 stack; they draw from Python's global ``random`` module in the same order as that torchvision
-generation (crop top, crop left, flip).  Training bookkeeping (``makeCheckpoint``,
-``savePerformance``) and video decoding (``extractEveryNthFrame``, ``convertVideosToFrames``; need
-``cv2``) are outside the hot path and not provided.
+generation (crop top, crop left, flip).  Training bookkeeping (``makeCheckpoint``, ``savePerformance``) and
+frame extraction (``extractEveryNthFrame``, ``convertVideosToFrames``) are provided too; the reference decodes
+with ``cv2.VideoCapture``, absent here, so ``iterVideoFrames`` reads RIFF/AVI Motion-JPEG itself and refuses
+other codecs by name.
 """
 from __future__ import division
 

@@ -34,7 +34,7 @@ def copy_first_layer(w_rgb, n_in):
     w_rgb = w_rgb.contiguous()
     out = torch.empty((w_rgb.shape[0], n_in, 3, 3), dtype=torch.float32, device=w_rgb.device)
     _ffi.check(_ffi.lib().va_copy_first_layer(_ffi.ctx(w_rgb.device.index), _ffi.ptr(w_rgb), w_rgb.shape[0], n_in,
-                                              _ffi.ptr(out), _ffi.stream_ptr()))
+                                              _ffi.ptr(out), _ffi.stream_ptr(w_rgb.device)))
     return out
 
 
@@ -91,9 +91,18 @@ class Vgg16Stream(object):
         with torch.cuda.device(dev):
             _ffi.check(_ffi.lib().va_vgg16_create(_ffi.ctx(dev.index), self.c_in, self.n_classes, self.desc_dim,
                                                   1 if dtype == "bf16" else 0,
-                                                  cw, cb, fw, fb, mean, std, _ffi.stream_ptr(), ctypes.byref(h)))
+                                                  cw, cb, fw, fb, mean, std, _ffi.stream_ptr(self.device), ctypes.byref(h)))
         self._h = h
         del keep
+
+    def _on_my_device(self, t, who):
+        """The packed weights, the va_ctx and the stream handed over all belong to ``self.device``."""
+        if t.device != self.device:
+            raise ValueError("Vgg16Stream.%s: tensor is on %s, the model on %s" % (who, t.device, self.device))
+
+    def set_option(self, option, value):
+        """``va_vgg16_set_option``: the explicit A/B and test switches of this handle (include/va.h)."""
+        _ffi.check(_ffi.lib().va_vgg16_set_option(self._h, int(option), int(value)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -115,6 +124,7 @@ class Vgg16Stream(object):
             raise ValueError("Vgg16Stream.forward: x must be [B,%d,224,224], got %s" % (self.c_in, tuple(x.shape)))
         if x.dtype not in (torch.float32, torch.uint8):
             raise ValueError("Vgg16Stream.forward: x must be float32 or uint8")
+        self._on_my_device(x, "forward")
         x = x.contiguous()
         B = x.shape[0]
         L = _ffi.lib()
@@ -124,7 +134,7 @@ class Vgg16Stream(object):
         desc = torch.empty((B, self.desc_dim), dtype=torch.float32, device=x.device)
         logits = torch.empty((B, self.n_classes), dtype=torch.float32, device=x.device)
         _ffi.check(L.va_vgg16_forward(self._h, _ffi.ptr(x), int(x.dtype == torch.uint8), B, _ffi.ptr(feat),
-                                      _ffi.ptr(desc), _ffi.ptr(logits), _ffi.ptr(ws), ws.numel(), _ffi.stream_ptr()))
+                                      _ffi.ptr(desc), _ffi.ptr(logits), _ffi.ptr(ws), ws.numel(), _ffi.stream_ptr(self.device)))
         return feat, desc, logits
 
 
@@ -134,13 +144,14 @@ class Vgg16Stream(object):
             raise ValueError("Vgg16Stream.features: x must be a CUDA tensor")
         if x.dim() != 4 or tuple(x.shape[1:]) != (self.c_in, 224, 224) or x.dtype not in (torch.float32, torch.uint8):
             raise ValueError("Vgg16Stream.features: x must be float32/uint8 [B,%d,224,224]" % self.c_in)
+        self._on_my_device(x, "features")
         x = x.contiguous()
         B = x.shape[0]
         L = _ffi.lib()
         ws = _workspace(L.va_vgg16_workspace_bytes(self._h, B), x.device, self.ws_slot)
         feat = torch.empty((B, 512, 7, 7), dtype=torch.float32, device=x.device)
         _ffi.check(L.va_vgg16_forward(self._h, _ffi.ptr(x), int(x.dtype == torch.uint8), B, _ffi.ptr(feat), None, None,
-                                      _ffi.ptr(ws), ws.numel(), _ffi.stream_ptr()))
+                                      _ffi.ptr(ws), ws.numel(), _ffi.stream_ptr(self.device)))
         return feat
 
     def classify(self, feat):
@@ -150,6 +161,7 @@ class Vgg16Stream(object):
             raise ValueError("Vgg16Stream.classify: feat must be a CUDA float32 tensor")
         if feat.dim() != 4 or tuple(feat.shape[1:]) != (512, 7, 7):
             raise ValueError("Vgg16Stream.classify: feat must be [B,512,7,7]")
+        self._on_my_device(feat, "classify")
         feat = feat.contiguous()
         B = feat.shape[0]
         L = _ffi.lib()
@@ -157,7 +169,7 @@ class Vgg16Stream(object):
         desc = torch.empty((B, self.desc_dim), dtype=torch.float32, device=feat.device)
         logits = torch.empty((B, self.n_classes), dtype=torch.float32, device=feat.device)
         _ffi.check(L.va_vgg16_classify(self._h, _ffi.ptr(feat), B, _ffi.ptr(desc), _ffi.ptr(logits), _ffi.ptr(ws),
-                                       ws.numel(), _ffi.stream_ptr()))
+                                       ws.numel(), _ffi.stream_ptr(self.device)))
         return desc, logits
 
 
@@ -165,7 +177,7 @@ class Vgg16Stream(object):
 
     def train_init(self):
         """Allocate and zero the momentum buffers (``tch.optim.SGD(..., momentum=...)``, Sheet03/spatialModel.py:116)."""
-        _ffi.check(_ffi.lib().va_vgg16_train_init(self._h, _ffi.stream_ptr()))
+        _ffi.check(_ffi.lib().va_vgg16_train_init(self._h, _ffi.stream_ptr(self.device)))
         self._train_ready = True
 
     def train_step(self, x, labels, lr, momentum, dropout_seed):
@@ -179,7 +191,9 @@ class Vgg16Stream(object):
             raise ValueError("Vgg16Stream.train_step: x must be a CUDA float32/uint8 tensor")
         if x.dim() != 4 or tuple(x.shape[1:]) != (self.c_in, 224, 224):
             raise ValueError("Vgg16Stream.train_step: x must be [B,%d,224,224], got %s" % (self.c_in, tuple(x.shape)))
+        self._on_my_device(x, "train_step")
         B = x.shape[0]
+        _check_labels(labels, self.n_classes, "Vgg16Stream.train_step")
         labels = labels.to(device=x.device, dtype=torch.int64).contiguous()
         if labels.dim() != 1 or labels.shape[0] != B:
             raise ValueError("Vgg16Stream.train_step: labels must be [B]")
@@ -193,7 +207,7 @@ class Vgg16Stream(object):
         desc = torch.empty((B, self.desc_dim), dtype=torch.float32, device=x.device)
         _ffi.check(L.va_vgg16_train_step(self._h, _ffi.ptr(x), int(x.dtype == torch.uint8), _ffi.ptr(labels), B, float(lr),
                                          float(momentum), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, _ffi.ptr(desc), _ffi.ptr(stats),
-                                         _ffi.ptr(ws), ws.numel(), _ffi.stream_ptr()))
+                                         _ffi.ptr(ws), ws.numel(), _ffi.stream_ptr(self.device)))
         return stats, desc
 
     def _state_tensors(self, device):
@@ -217,7 +231,7 @@ class Vgg16Stream(object):
         arr, arr4 = ctypes.c_void_p * 13, ctypes.c_void_p * 4
         _ffi.check(_ffi.lib().va_vgg16_export_state(self._h, int(bool(momentum)), arr(*[t.data_ptr() for t in cw]),
                                                     arr(*[t.data_ptr() for t in cb]), arr4(*[t.data_ptr() for t in fw]),
-                                                    arr4(*[t.data_ptr() for t in fb]), _ffi.stream_ptr()))
+                                                    arr4(*[t.data_ptr() for t in fb]), _ffi.stream_ptr(self.device)))
         return dict(conv_w=cw, conv_b=cb, fc_w=fw, fc_b=fb)
 
     def import_state(self, state, momentum=False):
@@ -240,7 +254,7 @@ class Vgg16Stream(object):
         arr, arr4 = ctypes.c_void_p * 13, ctypes.c_void_p * 4
         _ffi.check(_ffi.lib().va_vgg16_import_state(self._h, int(bool(momentum)), arr(*[p(t) for t in state["conv_w"]]),
                                                     arr(*[p(t) for t in state["conv_b"]]), arr4(*[p(t) for t in state["fc_w"]]),
-                                                    arr4(*[p(t) for t in state["fc_b"]]), _ffi.stream_ptr()))
+                                                    arr4(*[p(t) for t in state["fc_b"]]), _ffi.stream_ptr(self.device)))
         torch.cuda.current_stream().synchronize()  # `keep` must outlive the copies
         del keep
 
@@ -287,16 +301,29 @@ def _ffi_conv_cout(i):
     return (64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512)[i]
 
 
+def _check_labels(labels, n_classes, who):
+    """``nn.CrossEntropyLoss`` (Sheet03/spatialModel.py:114,219) refuses a target outside [0, C) ("Target 101 is out
+    of bounds"); the datasets return the list files' raw 1-based labels, so the full UCF-101 list
+    with ``nActionClasses = 101`` does trip this.  Labels still on the host (what a DataLoader hands over) are
+    checked here without touching the GPU; labels already on the device are not copied back -- for those the
+    kernels read nothing out of bounds and return a NaN loss."""
+    if isinstance(labels, torch.Tensor) and not labels.is_cuda and labels.numel() > 0:
+        lo, hi = int(labels.min()), int(labels.max())
+        if lo < 0 or hi >= n_classes:
+            raise ValueError("%s: Target %d is out of bounds for %d classes" % (who, hi if hi >= n_classes else lo, n_classes))
+
+
 def validate_batch(logits, labels):
     """(mean cross-entropy, number correct) of one batch on the device
     (Sheet03/spatialModel.py:219-221); returns a CUDA float32 tensor [2] without synchronising."""
     if not logits.is_cuda or logits.dtype != torch.float32 or logits.dim() != 2:
         raise ValueError("validate_batch: logits must be CUDA float32 [B,C]")
+    _check_labels(labels, logits.shape[1], "validate_batch")
     labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
     if labels.dim() != 1 or labels.shape[0] != logits.shape[0]:
         raise ValueError("validate_batch: labels must be [B]")
     logits = logits.contiguous()
     out = torch.empty(2, dtype=torch.float32, device=logits.device)
     _ffi.check(_ffi.lib().va_validate_batch(_ffi.ctx(logits.device.index), _ffi.ptr(logits), _ffi.ptr(labels),
-                                            logits.shape[0], logits.shape[1], _ffi.ptr(out), _ffi.stream_ptr()))
+                                            logits.shape[0], logits.shape[1], _ffi.ptr(out), _ffi.stream_ptr(logits.device)))
     return out
