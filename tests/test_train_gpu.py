@@ -18,10 +18,12 @@ def _relerr(a, b):
     return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
 
 
-# TOL_UPDATE bounds the WORST element, which a handful of flipped decisions sets.  A genuine gradient bug of that
-# size (a missing tap, a wrong slab, a mis-scaled bias gradient) would be wrong EVERYWHERE, so the typical element is
-# bounded separately and much tighter: root-mean-square error of a tensor's update relative to the RMS of the update.
-TOL_UPDATE_RMS = 2e-3
+# A flipped decision perturbs EVERY gradient below it by about the same relative amount (measured: max and RMS error
+# both 2e-3..4e-3 on conv layers 0..9, 2e-5 on layers 10..12 above the first flip), so TOL_UPDATE cannot tell a flip
+# from a genuine gradient bug of that size.  test_conv_updates_under_the_products_own_decisions removes the
+# ambiguity: the oracle back-propagates through the decisions the HIP forward pass actually took, and every update
+# must then agree to TOL_UPDATE_DECIDED.
+TOL_UPDATE_DECIDED = 5e-4
 
 
 def _rmserr(a, b):
@@ -71,10 +73,79 @@ def test_two_sgd_steps_match_autograd(c_in, B):
                 rms.append((e_rms, step, k, i))
                 print("step %d %-6s %2d: update err %.2e (rms %.2e)  momentum err %.2e" % (step, k, i, e_upd, e_rms, e_mom))
         assert max(worst)[0] < TOL_UPDATE, max(worst)
-        assert max(rms)[0] < TOL_UPDATE_RMS, max(rms)
+        assert max(rms)[0] < TOL_UPDATE, max(rms)
         tight = [e for e, _, k, i in worst if k.startswith("fc")]  # no pooling / ReLU decision below the classifier's own
         assert max(tight) < 5e-4, max(tight)
     m.close()
+
+
+@pytest.mark.parametrize("c_in,B", [(3, 2), (20, 3)])
+def test_conv_updates_under_the_products_own_decisions(c_in, B):
+    """One SGD step where the autograd oracle uses the ReLU masks and pooling arg-maxima of the HIP forward pass
+    (read from the training workspace: all 13 conv outputs stay there; va_vgg16_train_plan gives the offsets).  With
+    the decisions shared, nothing but fp32 summation order separates the two backward passes: every parameter update,
+    conv layers 0..9 included, must agree to TOL_UPDATE_DECIDED (max AND rms), and the decisions themselves must
+    differ from the oracle's own in at most a few elements per million."""
+    import ctypes
+    from oracle import train_oracle, vgg_oracle
+    from video_analytics_amd import _ffi, synth, vgg
+    torch.set_num_threads(8)
+    w = synth.synth_vgg16_weights(c_in=3, seed=4)
+    if c_in != 3:
+        w["conv_w"][0] = vgg_oracle.copy_first_layer(w["conv_w"][0], c_in)
+    lr, mu = 1e-4, 0.9
+    u = synth.hash_uniform(70, c_in, B * c_in * 224 * 224).reshape(B, c_in, 224, 224)
+    x = torch.from_numpy(u * 4.0 - 2.0)
+    labels = torch.tensor([(7 * i + 1) % 101 for i in range(B)], dtype=torch.int64)
+    m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256)
+    stats, _ = m.train_step(x.cuda(), labels.cuda(), lr, mu, 1000)
+    torch.cuda.synchronize()
+    off = (ctypes.c_ulonglong * 30)()
+    _ffi.check(_ffi.lib().va_vgg16_train_plan(m._h, B, off))
+    ws = [t for k, t in vgg._ws_cache.items() if "train" in str(k)][0]
+    ys, hw = [], 224
+    for i, v in enumerate([c for c in vgg_oracle.VGG16_CFG if c != "M"]):
+        n = B * hw * hw * v
+        y = ws[off[i]:off[i] + 4 * n].view(torch.float32).view(B, hw, hw, v).permute(0, 3, 1, 2).contiguous().cpu()
+        ys.append(y)
+        if off[13 + i]:
+            hw //= 2
+    dec = train_oracle.decisions_from_activations(ys)
+    # the product's decisions against the oracle's own: a handful of near-ties, not a different function
+    own = train_oracle.decisions_from_activations(
+        _conv_outputs(x, w["conv_w"], w["conv_b"]))
+    n_dec = sum(d["mask"].numel() for d in dec)
+    n_flip = sum(int((a["mask"] != b["mask"]).sum()) for a, b in zip(dec, own))
+    n_flip += sum(int((a["pool_idx"] != b["pool_idx"]).sum()) for a, b in zip(dec, own) if a["pool_idx"] is not None)
+    print("decisions that differ between the HIP and the torch-CPU forward pass: %d of %d" % (n_flip, n_dec))
+    assert n_flip <= max(8, n_dec // 100000), (n_flip, n_dec)
+    ora = train_oracle.TrainOracle(w, lr, mu)
+    loss_r, corr_r, _, _ = ora.step(x, labels, seed=1000, decisions=dec)
+    assert abs(float(stats.cpu()[0]) - loss_r) < 2e-4 * max(1.0, abs(loss_r))
+    got, ref = m.export_state(), ora.weights()
+    worst = []
+    for k in ("conv_w", "conv_b", "fc_w", "fc_b"):
+        for i, (g, r, o) in enumerate(zip(got[k], ref[k], w[k])):
+            e_max, e_rms = _relerr(g.cpu() - o, r - o), _rmserr(g.cpu() - o, r - o)
+            worst.append((max(e_max, e_rms), k, i))
+            print("%-6s %2d: update err %.2e (rms %.2e)" % (k, i, e_max, e_rms))
+    m.close()
+    assert max(worst)[0] < TOL_UPDATE_DECIDED, max(worst)
+
+
+def _conv_outputs(x, conv_w, conv_b):
+    import torch.nn.functional as F
+    from oracle import vgg_oracle
+    ys, h, i = [], x, 0
+    with torch.no_grad():
+        for v in vgg_oracle.VGG16_CFG:
+            if v == "M":
+                h = F.max_pool2d(h, 2, 2)
+            else:
+                h = F.relu(F.conv2d(h, conv_w[i], conv_b[i], padding=1))
+                ys.append(h)
+                i += 1
+    return ys
 
 
 def test_export_import_round_trip():
