@@ -153,8 +153,9 @@ typedef struct va_tvl1_params {
                          per CU; bits 4-7: 256x16, 128x32, 84x48, 64x64, two 4-wave workgroups per
                          CU).  Bit 8 (256): iterate every level with the streaming kernel (a wave carries a
                          128-column strip row by row through 10 iterations per pass) instead of the
-                         register tiles; fixed-iteration mode only.  0 (default) = library choice per
-                         level.  Results do not depend on it. */
+                         register tiles; fixed-iteration mode only.  Bit 9 (512): iterate every level that fits one
+                         strip (<= 256 columns) with the persistent row pipeline k_iter_rows, the others with the
+                         streaming kernel.  0 (default) = library choice per level.  Results do not depend on it. */
     /* Explicit tuning / test switches of the row pipeline (k_iter_stream); the library reads no environment variable.
        Results do not depend on any of them. */
     int stream_levels; /* -1 (default): the library decides per level; otherwise a bit set: bit s = pyramid level s
@@ -163,6 +164,12 @@ typedef struct va_tvl1_params {
                           one-wave (10 per pass) elsewhere; 1: one-wave pipeline everywhere */
     int stream_chunks; /* 0 (default): rows cut into as many chunks as fill the GPU; n > 0: n chunks (capped at h/32) */
     int stream_slots;  /* 0 (default): target number of strip x chunk x pair jobs per call (640 two-wave / 1024 one-wave) */
+    /* The persistent row pipeline (k_iter_rows: all `iters` iterations of a warp step in one launch, one workgroup per
+       pair; levels of at most 256 columns, fixed-iteration mode). */
+    int rows_levels;   /* -1 (default): the library decides per level; otherwise a bit set as stream_levels: bit s =
+                          level s iterates with k_iter_rows where it applies (takes precedence over stream_levels) */
+    int rows_cfg;      /* 0 (default): the library's pipeline shape; otherwise waves * 16 + levels per wave (one of the
+                          compiled shapes: 4x4, 2x8, 3x5, 4x3, 8x2, 2x6), i.e. waves x levels iterations per pass */
 } va_tvl1_params;
 
 void va_tvl1_default_params(va_tvl1_params* p);

@@ -19,7 +19,7 @@ def _frames(n_seq, n_frames, H, W, seed):
 
 
 # tuning fields of va_tvl1_params the oracle has no counterpart for (results must not depend on them)
-PRODUCT_ONLY = ("block_iters", "tile_mask", "stream_levels", "stream_waves", "stream_chunks", "stream_slots")
+PRODUCT_ONLY = ("block_iters", "tile_mask", "stream_levels", "stream_waves", "stream_chunks", "stream_slots", "rows_levels", "rows_cfg")
 
 
 def _run_both(oracle_tvl1, gray, **kw):
@@ -80,6 +80,53 @@ def test_streaming_kernel_bit_exact(oracle_tvl1, H, W, nch):
         ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=warps, nscales=nscales, tile_mask=1 << 8,
                              stream_chunks=nch)
         assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
+ROWS_SHAPES = [0, 4 * 16 + 4, 2 * 16 + 8, 3 * 16 + 5, 4 * 16 + 3, 8 * 16 + 2, 2 * 16 + 6]
+
+
+@pytest.mark.parametrize("H,W", [(48, 64), (100, 64), (224, 224), (57, 131), (179, 179), (143, 143), (114, 114), (91, 91),
+                                 (33, 130), (24, 16), (129, 225), (200, 256), (40, 190)])
+def test_persistent_row_pipeline_bit_exact(oracle_tvl1, H, W):
+    # tile_mask bit 9 forces k_iter_rows (all iterations of a warp step in one launch, passes chained inside the kernel)
+    # on every level it applies to: 2, 3 and 4 pixels per lane (widths up to 128 / 192 / 256), ragged widths with pitch
+    # padding, heights just above and below the minimum for the default shape (levels that do not qualify fall back
+    # to k_iter_stream), iteration counts below one pass (10), with a short first pass (23 = 7 + 16), several full passes
+    # (50 = 2 + 3 x 16) -- bit-identical to the oracle each time
+    gray = _frames(2, 3, H, W, seed=3 * H + W)
+    for iters, warps, nscales in ((10, 1, 1), (23, 2, 3), (50, 1, 2)):
+        ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=warps, nscales=nscales, tile_mask=1 << 9)
+        assert np.array_equal(out, ref), "iters %d: max abs diff %g" % (iters, np.abs(out - ref).max())
+
+
+@pytest.mark.parametrize("cfg", ROWS_SHAPES)
+@pytest.mark.parametrize("n", [224, 179, 91])
+def test_every_row_pipeline_shape_bit_exact(oracle_tvl1, cfg, n):
+    # every compiled waves x levels shape on the benchmark's 4-, 3- and 2-pixel-per-lane levels; 37 iterations = a short
+    # first pass plus full passes for every shape's depth (8 .. 16); also the 1-ulp arithmetic variant against the
+    # register tiles' (the same operations in both kernels)
+    from video_analytics_amd import flow as vflow
+    gray = _frames(3, 2, n, n, seed=n + cfg)
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=37, warps=2, nscales=1, tile_mask=1 << 9, rows_cfg=cfg)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+    fast = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=37, warps=2, nscales=1, tile_mask=1 << 9, rows_cfg=cfg, fast_math=1)
+    tiles = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=37, warps=2, nscales=1, tile_mask=0xFF, fast_math=1)
+    assert torch.equal(fast, tiles)
+
+
+def test_row_pipeline_full_schedule_and_mixed_levels(oracle_tvl1):
+    # the benchmark schedule (5 scales x 5 warps x 300 iterations: 19 chained passes per launch) on the benchmark's
+    # frame size, all levels on k_iter_rows; then mixed with the other two kernels level by level (layouts convert at
+    # the level transitions)
+    from video_analytics_amd import flow as vflow
+    gray = _frames(2, 2, 224, 224, seed=91)
+    ref = oracle_tvl1.tvl1_flow(gray.numpy(), oracle_tvl1.default_params(epsilon=0.0), nthreads=8)
+    out = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, tile_mask=1 << 9).cpu().numpy()
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+    ref = oracle_tvl1.tvl1_flow(gray.numpy(), oracle_tvl1.default_params(epsilon=0.0, iters=25, warps=2), nthreads=8)
+    for rows, stream in ((0b10101, 0b01000), (0b01010, 0b00001), (0b11111, 0)):
+        out = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=25, warps=2, rows_levels=rows, stream_levels=stream).cpu().numpy()
+        assert np.array_equal(out, ref), "rows %d stream %d: max abs diff %g" % (rows, stream, np.abs(out - ref).max())
 
 
 def test_streaming_kernel_fast_math_and_mixed_levels(oracle_tvl1):

@@ -44,6 +44,8 @@ class Tvl1Params(ctypes.Structure):
         ("stream_waves", ctypes.c_int),
         ("stream_chunks", ctypes.c_int),
         ("stream_slots", ctypes.c_int),
+        ("rows_levels", ctypes.c_int),
+        ("rows_cfg", ctypes.c_int),
     ]
 
 

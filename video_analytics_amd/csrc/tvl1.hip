@@ -947,6 +947,419 @@ __global__ void __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(2
     }
 }
 
+// ---------------------------------------------------------------- persistent row pipeline ------
+//
+// k_iter_rows: ALL `iters` inner iterations of one warp step in ONE launch, for levels that fit a single strip
+// (pitch <= 64 * PPL columns, PPL = 2, 3 or 4 pixels per lane: no x halo at all).  One workgroup owns one pair; its NWV
+// waves form the time-skewed row pipeline of k_iter_stream (wave W holds levels W*KH .. W*KH + KH - 1, rows are handed
+// from wave to wave through a double-buffered LDS row, one LDS-only barrier per step), but the pipeline never drains
+// between passes: the rows of pass n + 1 (read back from the buffer pass n wrote, K = NWV*KH iterations earlier in
+// time) follow the last row of pass n immediately, so the triangular fill/drain of a pass is paid once per launch
+// instead of once per K iterations, and there is no y halo and no launch boundary inside a warp step.
+//
+//  * Row identity travels with the row as one scalar: id = pass << 20 | ring slot << 14 | row (-1 = no row).  A level
+//    that holds a row emits it (one iteration on) when the next row arrives and keeps the arrival; a level that is not
+//    active for a row (its index >= the pass's depth) hands it on untouched.  Everything about identity is SALU work.
+//  * iters = K0 + (N - 1) K with the SHORT pass first: levels >= K0 are inactive for pass 0 and still hold their
+//    zero-initialised state when pass 1 reaches them, exactly as at the start of the kernel.
+//  * The image's last row is flushed by whatever row follows it (row 0 of the next pass, or dummy rows after the
+//    last pass): its forward y difference is multiplied by my = 0 whenever the arriving row has index 0.  A level in
+//    its initial state emits an exact zero row with no identity, which nobody stores.
+//  * Pass n + 1 reads row r at least h - K - NWV - 2 steps after pass n stored it; both happen on the same CU (one
+//    workgroup), whose vector L1 is write-through and coherent for its own waves: the storing wave drains its older
+//    stores (s_waitcnt vmcnt) before each step's barrier, nothing else is needed (no agent-scope fence).
+//  * The per-warp constants of the K + NWV rows in flight sit in an LDS ring written by the loading wave.
+// Same arithmetic as k_iter_tile / k_iter_stream, operation for operation: results are bit-identical.
+template <int N>
+struct Row {
+    static constexpr int NP = N / 2, NT = N & 1;
+    f2 p[NP > 0 ? NP : 1];
+    float t;
+};
+template <int N>
+__device__ __forceinline__ Row<N> row_splat(float v)
+{
+    Row<N> r;
+#pragma clang loop unroll(full)
+    for (int j = 0; j < Row<N>::NP; ++j) r.p[j] = splat(v);
+    r.t = v;
+    return r;
+}
+template <int N>
+__device__ __forceinline__ float row_get(const Row<N>& r, int i)
+{
+    return i < 2 * Row<N>::NP ? ((i & 1) ? r.p[i >> 1].y : r.p[i >> 1].x) : r.t;
+}
+template <int N>
+__device__ __forceinline__ void row_set(Row<N>& r, int i, float v)
+{
+    if (i < 2 * Row<N>::NP) {
+        if (i & 1) r.p[i >> 1].y = v;
+        else r.p[i >> 1].x = v;
+    } else {
+        r.t = v;
+    }
+}
+#define VA_ROW_OP(NAME, ARGS, PK, SC)                                   \
+    template <int N>                                                    \
+    __device__ __forceinline__ Row<N> NAME ARGS                         \
+    {                                                                   \
+        Row<N> r;                                                       \
+        _Pragma("clang loop unroll(full)") for (int j = 0; j < Row<N>::NP; ++j) r.p[j] = PK; \
+        r.t = 0.0f;                                                     \
+        if constexpr (Row<N>::NT) r.t = SC;                             \
+        return r;                                                       \
+    }
+VA_ROW_OP(r_fma, (const Row<N>& a, const Row<N>& b, const Row<N>& c), pk_fma(a.p[j], b.p[j], c.p[j]), fmaf(a.t, b.t, c.t))
+VA_ROW_OP(r_fma_s, (float s, const Row<N>& b, const Row<N>& c), pk_fma(splat(s), b.p[j], c.p[j]), fmaf(s, b.t, c.t))
+VA_ROW_OP(r_fma_c, (const Row<N>& a, const Row<N>& b, float c), pk_fma(a.p[j], b.p[j], splat(c)), fmaf(a.t, b.t, c))
+VA_ROW_OP(r_mul, (const Row<N>& a, const Row<N>& b), a.p[j] * b.p[j], a.t * b.t)
+VA_ROW_OP(r_mul_s, (const Row<N>& a, float s), a.p[j] * splat(s), a.t * s)
+VA_ROW_OP(r_negmul, (const Row<N>& a, const Row<N>& b), -a.p[j] * b.p[j], -a.t * b.t)
+VA_ROW_OP(r_add, (const Row<N>& a, const Row<N>& b), a.p[j] + b.p[j], a.t + b.t)
+VA_ROW_OP(r_sub, (const Row<N>& a, const Row<N>& b), a.p[j] - b.p[j], a.t - b.t)
+VA_ROW_OP(r_med3, (const Row<N>& a, float lo, float hi),
+          (f2{__builtin_amdgcn_fmed3f(a.p[j].x, lo, hi), __builtin_amdgcn_fmed3f(a.p[j].y, lo, hi)}), __builtin_amdgcn_fmed3f(a.t, lo, hi))
+#undef VA_ROW_OP
+// scalar twins of sqrt_exact_pk / rcp_exact_pk (the same operations on one element: bit-identical)
+__device__ __forceinline__ float sqrt_exact_s(float s)
+{
+    const float y = __builtin_amdgcn_rsqf(s);
+    const float g = s * y, h = y * 0.5f;
+    const float d = fmaf(-g, g, s);
+    return fmaf(d, h, g);
+}
+__device__ __forceinline__ float rcp_exact_s(float d)
+{
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float e = fmaf(-d, r, 1.0f);
+    return fmaf(e, r, r);
+}
+template <int N, bool FAST>
+__device__ __forceinline__ Row<N> r_sqrt(const Row<N>& s)
+{
+    Row<N> r;
+#pragma clang loop unroll(full)
+    for (int j = 0; j < Row<N>::NP; ++j)
+        r.p[j] = FAST ? f2{__builtin_amdgcn_sqrtf(s.p[j].x), __builtin_amdgcn_sqrtf(s.p[j].y)} : sqrt_exact_pk(s.p[j]);
+    r.t = 0.0f;
+    if constexpr (Row<N>::NT) r.t = FAST ? __builtin_amdgcn_sqrtf(s.t) : sqrt_exact_s(s.t);
+    return r;
+}
+template <int N, bool FAST>
+__device__ __forceinline__ Row<N> r_rcp(const Row<N>& d)
+{
+    Row<N> r;
+#pragma clang loop unroll(full)
+    for (int j = 0; j < Row<N>::NP; ++j)
+        r.p[j] = FAST ? f2{__builtin_amdgcn_rcpf(d.p[j].x), __builtin_amdgcn_rcpf(d.p[j].y)} : rcp_exact_pk(d.p[j]);
+    r.t = 0.0f;
+    if constexpr (Row<N>::NT) r.t = FAST ? __builtin_amdgcn_rcpf(d.t) : rcp_exact_s(d.t);
+    return r;
+}
+// backward / forward x differences of a lane's N consecutive pixels; the neighbour lane supplies the pixel across the
+// lane boundary (0 beyond the wave's ends: the divergence's border rule on the left, masked by mx on the right)
+template <int N>
+__device__ __forceinline__ Row<N> r_diff_back(const Row<N>& a)
+{
+    Row<N> d;
+    d.t = 0.0f;
+    float prev = dpp_from_left(row_get(a, N - 1));
+#pragma clang loop unroll(full)
+    for (int i = 0; i < N; ++i) {
+        const float cur = row_get(a, i);
+        row_set(d, i, sub_s(cur, prev));
+        prev = cur;
+    }
+    return d;
+}
+template <int N>
+__device__ __forceinline__ Row<N> r_diff_fwd(const Row<N>& a)
+{
+    Row<N> d;
+    d.t = 0.0f;
+    const float right = dpp_from_right(row_get(a, 0));
+#pragma clang loop unroll(full)
+    for (int i = 0; i < N; ++i) row_set(d, i, sub_s(i < N - 1 ? row_get(a, i + 1 < N ? i + 1 : 0) : right, row_get(a, i)));
+    return d;
+}
+
+struct RowsArgs {
+    const float* ro;
+    float* st;            // the lower of the two state buffers (pair-major planes)
+    unsigned delta[2];    // byte offset of state buffer 0 / 1 from `st`
+    size_t plane;
+    int w, h, pitch;
+    int K, K0, N;         // iterations of a full pass (<= NWV*KH), of the first pass (1..K), number of passes
+    int cur;              // buffer index holding the input of pass 0
+    int pair0;
+    float l_t, taut, theta;
+};
+
+template <int PPL> struct RowIo;
+template <> struct RowIo<2> {
+    typedef unsigned V __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ V ld(__amdgpu_buffer_rsrc_t r, int vo, int so) { return __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0); }
+    static __device__ __forceinline__ void st(V v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b64(v, r, vo, so, 0); }
+};
+template <> struct RowIo<3> {
+    typedef unsigned V __attribute__((ext_vector_type(3)));
+    static __device__ __forceinline__ V ld(__amdgpu_buffer_rsrc_t r, int vo, int so) { return __builtin_amdgcn_raw_buffer_load_b96(r, vo, so, 0); }
+    static __device__ __forceinline__ void st(V v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b96(v, r, vo, so, 0); }
+};
+template <> struct RowIo<4> {
+    typedef unsigned V __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ V ld(__amdgpu_buffer_rsrc_t r, int vo, int so) { return __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0); }
+    static __device__ __forceinline__ void st(V v, __amdgpu_buffer_rsrc_t r, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b128(v, r, vo, so, 0); }
+};
+template <int N>
+__device__ __forceinline__ Row<N> row_load(__amdgpu_buffer_rsrc_t r, int vo, int so)
+{
+    const typename RowIo<N>::V v = RowIo<N>::ld(r, vo, so);
+    Row<N> o;
+    o.t = 0.0f;
+#pragma clang loop unroll(full)
+    for (int i = 0; i < N; ++i) row_set(o, i, __uint_as_float(v[i]));
+    return o;
+}
+template <int N>
+__device__ __forceinline__ void row_store(const Row<N>& o, __amdgpu_buffer_rsrc_t r, int vo, int so)
+{
+    typename RowIo<N>::V v;
+#pragma clang loop unroll(full)
+    for (int i = 0; i < N; ++i) v[i] = __float_as_uint(row_get(o, i));
+    RowIo<N>::st(v, r, vo, so);
+}
+
+constexpr int kRowIdRowBits = 14, kRowIdSlotBits = 6;  // id = pass << 20 | slot << 14 | row
+
+template <int PPL, int KH, int NWV, bool FAST>
+__global__ void __launch_bounds__(NWV * 64) k_iter_rows(RowsArgs a)
+{
+    typedef Row<PPL> R;
+    constexpr int NP = R::NP, NT = R::NT, KMAX = KH * NWV, NRING = KMAX + NWV, NB = NWV > 1 ? NWV - 1 : 1;
+    static_assert(NRING <= (1 << kRowIdSlotBits), "ring slots must fit the row identity");
+    __shared__ f2 ringP[NRING][kNF_RO][NP][64];
+    __shared__ float ringT[NRING][kNF_RO][NT ? 64 : 1];
+    __shared__ f2 ifP[NB][2][kNF_STATE][NP][64];
+    __shared__ float ifT[NB][2][kNF_STATE][NT ? 64 : 1];
+    __shared__ int ifId[NB][2];
+
+    const int pair = a.pair0 + (int)blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int w = a.w, h = a.h, pitch = a.pitch, K = a.K, K0 = a.K0, NPASS = a.N;
+    const int x0 = PPL * lane;
+    const bool colok = x0 < pitch;  // the pitch is a multiple of PPL: a lane is wholly inside a row or wholly outside
+    const int loff = colok ? x0 * (int)sizeof(float) : 0;
+    const int planeb = (int)(a.plane * sizeof(float)), pitchb = pitch * (int)sizeof(float);
+    const unsigned dmax = a.delta[0] > a.delta[1] ? a.delta[0] : a.delta[1];
+    const __amdgpu_buffer_rsrc_t rs_ro = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.ro + (size_t)pair * kNF_RO * a.plane), 0, kNF_RO * planeb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc(
+        a.st + (size_t)pair * kNF_STATE * a.plane, 0, (int)dmax + kNF_STATE * planeb, 0x00020000);
+
+    R mx;
+    mx.t = 0.0f;
+#pragma clang loop unroll(full)
+    for (int i = 0; i < PPL; ++i) row_set(mx, i, x0 + i < w - 1 ? 1.0f : 0.0f);
+    const float l_t = a.l_t, taut = a.taut, theta = a.theta;
+    const R zero = row_splat<PPL>(0.0f);
+
+    if constexpr (NWV > 1) {
+        if (wv < NWV - 1) {
+#pragma clang loop unroll(full)
+            for (int b = 0; b < 2; ++b) {
+#pragma clang loop unroll(full)
+                for (int f = 0; f < kNF_STATE; ++f) {
+#pragma clang loop unroll(full)
+                    for (int j = 0; j < NP; ++j) ifP[wv][b][f][j][lane] = splat(0.0f);
+                    if constexpr (NT) ifT[wv][b][f][lane] = 0.0f;
+                }
+                if (lane == 0) ifId[wv][b] = -1;
+            }
+        }
+        __syncthreads();
+    }
+
+    R P11[KH], P12[KH], P21[KH], P22[KH], U1[KH], U2[KH];
+    int sid[KH];
+#pragma clang loop unroll(full)
+    for (int t = 0; t < KH; ++t) {
+        P11[t] = P12[t] = P21[t] = P22[t] = U1[t] = U2[t] = zero;
+        sid[t] = -1;
+    }
+
+    // loader (wave 0): the row of the current step and the prefetched data of that row
+    int ln = 0, lr = 0, lslot = 0;
+    R nst[kNF_STATE], nro[kNF_RO];
+#pragma clang loop unroll(full)
+    for (int f = 0; f < kNF_STATE; ++f) nst[f] = zero;
+#pragma clang loop unroll(full)
+    for (int f = 0; f < kNF_RO; ++f) nro[f] = zero;
+    if (wv == 0) {
+        const int so = (int)a.delta[a.cur & 1];
+#pragma clang loop unroll(full)
+        for (int f = 0; f < kNF_STATE; ++f) nst[f] = row_load<PPL>(rs_st, loff, so + f * planeb);
+#pragma clang loop unroll(full)
+        for (int f = 0; f < kNF_RO; ++f) nro[f] = row_load<PPL>(rs_ro, loff, f * planeb);
+    }
+
+    const int nsteps = NPASS * h + KMAX + NWV + 1;
+    for (int s = 0; s < nsteps; ++s) {
+        R c[kNF_STATE];
+        int ids[KH + 1];
+        if (wv == 0) {
+#pragma clang loop unroll(full)
+            for (int f = 0; f < kNF_STATE; ++f) c[f] = nst[f];
+            ids[0] = (ln << (kRowIdRowBits + kRowIdSlotBits)) | (lslot << kRowIdRowBits) | lr;
+#pragma clang loop unroll(full)
+            for (int f = 0; f < kNF_RO; ++f) {
+#pragma clang loop unroll(full)
+                for (int j = 0; j < NP; ++j) ringP[lslot][f][j][lane] = nro[f].p[j];
+                if constexpr (NT) ringT[lslot][f][lane] = nro[f].t;
+            }
+            // the next row: row 0 of the next pass after row h - 1; after the last pass dummy rows (the last pass's input
+            // row h - 1 again: finite values) that only push the last rows through the levels
+            int nn = ln, nr = lr + 1;
+            if (nn < NPASS && nr == h) {
+                nr = 0;
+                ++nn;
+            }
+            const int pn = nn < NPASS ? nn : NPASS - 1, pr = nn < NPASS ? nr : h - 1;
+            const int so = (int)a.delta[(a.cur ^ pn) & 1] + pr * pitchb;
+#pragma clang loop unroll(full)
+            for (int f = 0; f < kNF_STATE; ++f) nst[f] = row_load<PPL>(rs_st, loff, so + f * planeb);
+#pragma clang loop unroll(full)
+            for (int f = 0; f < kNF_RO; ++f) nro[f] = row_load<PPL>(rs_ro, loff, pr * pitchb + f * planeb);
+            ln = nn;
+            lr = nr;
+            lslot = lslot + 1 == NRING ? 0 : lslot + 1;
+            __builtin_amdgcn_sched_barrier(0);  // the loads stay at the top of the step: a whole step hides their latency
+        } else {
+            const int b = (s + 1) & 1, wb = wv - 1;  // what the wave before wrote in step s - 1
+#pragma clang loop unroll(full)
+            for (int f = 0; f < kNF_STATE; ++f) {
+#pragma clang loop unroll(full)
+                for (int j = 0; j < NP; ++j) c[f].p[j] = ifP[wb][b][f][j][lane];
+                c[f].t = 0.0f;
+                if constexpr (NT) c[f].t = ifT[wb][b][f][lane];
+            }
+            ids[0] = __builtin_amdgcn_readfirstlane(ifId[wb][b]);
+        }
+        // identity pre-pass (scalar): which levels of this wave work in this step, on which rows
+        bool act[KH];
+#pragma clang loop unroll(full)
+        for (int t = 0; t < KH; ++t) {
+            const int in = ids[t];
+            const int kof = (in >> (kRowIdRowBits + kRowIdSlotBits)) == 0 ? K0 : K;
+            act[t] = in >= 0 && wv * KH + t < kof;
+            ids[t + 1] = act[t] ? sid[t] : in;
+            sid[t] = act[t] ? in : sid[t];
+        }
+        auto consts = [&](int t, R (&q)[kNF_RO]) __attribute__((always_inline)) {
+            const int slot = act[t] ? (ids[t] >> kRowIdRowBits) & ((1 << kRowIdSlotBits) - 1) : 0;
+#pragma clang loop unroll(full)
+            for (int f = 0; f < kNF_RO; ++f) {
+#pragma clang loop unroll(full)
+                for (int j = 0; j < NP; ++j) q[f].p[j] = ringP[slot][f][j][lane];
+                q[f].t = 0.0f;
+                if constexpr (NT) q[f].t = ringT[slot][f][lane];
+            }
+        };
+        R q[kNF_RO];
+        consts(0, q);
+#pragma clang loop unroll(full)
+        for (int t = 0; t < KH; ++t) {
+            R nq[kNF_RO];
+            if (t + 1 < KH) {
+                consts(t + 1 < KH ? t + 1 : 0, nq);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (act[t]) {
+                // phase A on the arriving row (time t), phase B on the row the level holds (its lower neighbour is the
+                // row just computed); the level keeps the arriving p and the new u and emits (old u, new p) = the held row
+                // one iteration on.  k_iter_tile's arithmetic, operation for operation.
+                const float my = (ids[t] & ((1 << kRowIdRowBits) - 1)) != 0 ? 1.0f : 0.0f;
+                const R &wx = q[0], &wy = q[1], &rc = q[2], &ig = q[3];
+                const R dx11 = r_diff_back(c[2]), dx21 = r_diff_back(c[4]);
+                const R div1 = r_add(dx11, r_sub(c[3], P12[t]));
+                const R div2 = r_add(dx21, r_sub(c[5], P22[t]));
+                const R rho = r_fma(wy, c[1], r_fma(wx, c[0], rc));
+                const R tt = r_negmul(rho, ig);
+                const R fi = r_med3(tt, -l_t, l_t);
+                const R v1 = r_fma(fi, wx, c[0]);
+                const R v2 = r_fma(fi, wy, c[1]);
+                const R n1 = r_fma_s(theta, div1, v1);
+                const R n2 = r_fma_s(theta, div2, v2);
+                const R d1x = r_diff_fwd(U1[t]), d2x = r_diff_fwd(U2[t]);
+                const R u1x = r_mul(d1x, mx), u1y = r_mul_s(r_sub(n1, U1[t]), my);
+                const R u2x = r_mul(d2x, mx), u2y = r_mul_s(r_sub(n2, U2[t]), my);
+                const R s1 = r_fma(u1y, u1y, r_fma_c(u1x, u1x, kSqrtReg));
+                const R s2 = r_fma(u2y, u2y, r_fma_c(u2x, u2x, kSqrtReg));
+                R q1, q2;
+                if constexpr (FAST) {
+                    const R d1 = r_fma_s(taut, r_sqrt<PPL, true>(s1), row_splat<PPL>(1.0f));
+                    const R d2 = r_fma_s(taut, r_sqrt<PPL, true>(s2), row_splat<PPL>(1.0f));
+                    q1 = r_rcp<PPL, true>(d1);
+                    q2 = r_rcp<PPL, true>(d2);
+                } else {
+                    const R d1 = r_fma_s(taut, r_sqrt<PPL, false>(s1), row_splat<PPL>(1.0f));
+                    const R d2 = r_fma_s(taut, r_sqrt<PPL, false>(s2), row_splat<PPL>(1.0f));
+                    const R rinv = r_rcp<PPL, false>(r_mul(d1, d2));
+                    q1 = r_mul(d2, rinv);
+                    q2 = r_mul(d1, rinv);
+                }
+                const R o11 = r_mul(r_fma_s(taut, u1x, P11[t]), q1);
+                const R o12 = r_mul(r_fma_s(taut, u1y, P12[t]), q1);
+                const R o21 = r_mul(r_fma_s(taut, u2x, P21[t]), q2);
+                const R o22 = r_mul(r_fma_s(taut, u2y, P22[t]), q2);
+                const R ou1 = U1[t], ou2 = U2[t];
+                P11[t] = c[2];
+                P12[t] = c[3];
+                P21[t] = c[4];
+                P22[t] = c[5];
+                U1[t] = n1;
+                U2[t] = n2;
+                c[0] = ou1;
+                c[1] = ou2;
+                c[2] = o11;
+                c[3] = o12;
+                c[4] = o21;
+                c[5] = o22;
+            }
+            if (t + 1 < KH) {
+#pragma clang loop unroll(full)
+                for (int f = 0; f < kNF_RO; ++f) q[f] = nq[f];
+            }
+        }
+        const int out = ids[KH];
+        if (NWV > 1 && wv < NWV - 1) {
+            const int b = s & 1;
+#pragma clang loop unroll(full)
+            for (int f = 0; f < kNF_STATE; ++f) {
+#pragma clang loop unroll(full)
+                for (int j = 0; j < NP; ++j) ifP[wv][b][f][j][lane] = c[f].p[j];
+                if constexpr (NT) ifT[wv][b][f][lane] = c[f].t;
+            }
+            if (lane == 0) ifId[wv][b] = out;
+        } else {
+            const int on = out >> (kRowIdRowBits + kRowIdSlotBits);
+            if (out >= 0 && on < NPASS && colok) {
+                const int so = (int)a.delta[(a.cur ^ (on + 1)) & 1] + (out & ((1 << kRowIdRowBits) - 1)) * pitchb;
+#pragma clang loop unroll(full)
+                for (int f = 0; f < kNF_STATE; ++f) row_store<PPL>(c[f], rs_st, loff, so + f * planeb);
+            }
+        }
+        if constexpr (NWV > 1) {
+            // The storing wave drains every store older than this step's (the next pass reads them back, h - K - NWV - 2
+            // steps from now at the earliest); then the hand-over barrier: LDS traffic only.
+            if (wv == NWV - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kNF_STATE) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host side -------------------
 
 struct TileCfg {
@@ -1104,6 +1517,83 @@ bool level_streams(const va_tvl1_params* p, bool eps, int s, int w, int h, size_
     return (double)w >= 0.75 * 128.0 * sp.nsx && (double)w * h >= 40000.0;
 }
 
+// ---- k_iter_rows: which levels, which pipeline shape
+constexpr int kRowsBit = 1 << 9;  // va_tvl1_params.tile_mask bit: iterate with k_iter_rows wherever it applies
+struct RowsPick {
+    int ppl, nwv, kh, K, K0, N;
+};
+// pipeline shapes compiled in (waves x levels per wave); rows_cfg = waves * 16 + levels per wave, 0 = the default
+constexpr int kRowsShapes[][2] = {{4, 4}, {2, 8}, {3, 5}, {4, 3}, {8, 2}, {2, 6}};
+constexpr int kNumRowsShapes = (int)(sizeof(kRowsShapes) / sizeof(kRowsShapes[0]));
+// LDS of one k_iter_rows workgroup: the ring of per-warp constants (K + NWV rows) + the double-buffered hand-over rows
+constexpr int rows_lds_bytes(int ppl, int nwv, int kh)
+{
+    return (nwv * kh + nwv) * kNF_RO * ppl * 256 + (nwv > 1 ? nwv - 1 : 1) * 2 * (kNF_STATE * ppl * 256 + 4);
+}
+constexpr int kRowsLdsMax = 160 * 1024 - 512;
+bool pick_rows(const va_tvl1_params* p, int h, int pitch, RowsPick& rp)
+{
+    int nwv = kRowsShapes[0][0], kh = kRowsShapes[0][1];
+    if (p->rows_cfg > 0) {
+        nwv = p->rows_cfg >> 4;
+        kh = p->rows_cfg & 15;
+    }
+    bool known = false;
+    for (int i = 0; i < kNumRowsShapes; ++i) known = known || (kRowsShapes[i][0] == nwv && kRowsShapes[i][1] == kh);
+    if (!known) return false;
+    rp.ppl = pitch <= 128 ? 2 : pitch <= 192 ? 3 : 4;
+    if (pitch > 256) return false;
+    rp.nwv = nwv;
+    rp.kh = kh;
+    if (rows_lds_bytes(rp.ppl, nwv, kh) > kRowsLdsMax) return false;
+    const int Kfull = nwv * kh;
+    rp.K = p->iters < Kfull ? p->iters : Kfull;
+    rp.N = va_cdiv(p->iters, rp.K);
+    rp.K0 = p->iters - (rp.N - 1) * rp.K;
+    if (rp.N >= 2047) return false;                 // the pass index must fit the row identity
+    // pass n + 1 reads a row back at least two steps after pass n stored it
+    return h >= Kfull + nwv + 4 && h < (1 << kRowIdRowBits);
+}
+
+enum { LK_TILE = 0, LK_STREAM = 1, LK_ROWS = 2 };
+bool level_streams(const va_tvl1_params* p, bool eps, int s, int w, int h, size_t plane);
+// Which kernel iterates level s.  Explicit choices first (tests, experiments), then the measured default.
+int level_kernel(const va_tvl1_params* p, bool eps, int s, int w, int h, int pitch, size_t plane, RowsPick* rp)
+{
+    RowsPick tmp{};
+    if (!rp) rp = &tmp;
+    if (eps || (double)plane * kNF_STATE * sizeof(float) >= 2147483648.0) return LK_TILE;
+    const bool rows_ok = pick_rows(p, h, pitch, *rp);
+    if (p->tile_mask & kRowsBit) return rows_ok ? LK_ROWS : LK_STREAM;
+    if (p->tile_mask != 0) return level_streams(p, eps, s, w, h, plane) ? LK_STREAM : LK_TILE;
+    if (p->rows_levels >= 0 || p->stream_levels >= 0) {
+        if (p->rows_levels >= 0 && ((p->rows_levels >> s) & 1) && rows_ok) return LK_ROWS;
+        return p->stream_levels >= 0 && ((p->stream_levels >> s) & 1) ? LK_STREAM : LK_TILE;
+    }
+    return level_streams(p, eps, s, w, h, plane) ? LK_STREAM : LK_TILE;
+}
+
+template <int PPL, bool FAST>
+int launch_rows(const RowsPick& rp, const RowsArgs& a, int npairs, hipStream_t st)
+{
+#define VA_ROWS_CASE(NWV_, KH_)                                                           \
+    if constexpr (rows_lds_bytes(PPL, NWV_, KH_) <= kRowsLdsMax) {                        \
+        if (rp.nwv == NWV_ && rp.kh == KH_) {                                             \
+            k_iter_rows<PPL, KH_, NWV_, FAST><<<npairs, NWV_ * 64, 0, st>>>(a);           \
+            return VA_OK;                                                                 \
+        }                                                                                 \
+    }
+    VA_ROWS_CASE(4, 4)
+    VA_ROWS_CASE(2, 8)
+    VA_ROWS_CASE(3, 5)
+    VA_ROWS_CASE(4, 3)
+    VA_ROWS_CASE(8, 2)
+    VA_ROWS_CASE(2, 6)
+#undef VA_ROWS_CASE
+    va_set_error("va_tvl1_flow: row pipeline shape %dx%d is not compiled in", rp.nwv, rp.kh);
+    return VA_ERR_INVALID;
+}
+
 // Pairs per chunk of a level: the iteration launches of a chunk re-read what the previous launch wrote, so a chunk
 // whose state (64 B per pixel) stays within ~150 MB (70, 110, 200 MB measured slower) is served largely by the Infinity Cache (measured on the 179^2
 // and 143^2 levels of the benchmark: -4 % each).  No chunking where a chunk could not fill the GPU.
@@ -1117,6 +1607,10 @@ int chunk_pairs(int lw, int lh, const TilePick& tp, int NP)
     const int n = va_cdiv(NP, cp_mem);
     return va_cdiv(NP, n);
 }
+
+// Row pitch in floats: a multiple of 12, so that rows start 16-byte aligned (k_iter_tile's 4-pixel runs) and a lane's 2,
+// 3 or 4 consecutive pixels (k_iter_stream, k_iter_rows) never straddle the end of a row.
+int level_pitch(int w) { return (w + 11) / 12 * 12; }
 
 struct Plan {
     int ns, ws[kMaxScales], hs[kMaxScales], pitch[kMaxScales];
@@ -1151,7 +1645,9 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
     VA_CHECK_ARG(p->tau > 0.0f && p->lambda > 0.0f && p->theta > 0.0f, "va_tvl1: tau, lambda, theta must be > 0");
     VA_CHECK_ARG(p->block_iters >= 0 && p->block_iters <= 64, "va_tvl1: block_iters must be in [0,64]");
     VA_CHECK_ARG(p->fast_math == 0 || p->fast_math == 1, "va_tvl1: fast_math must be 0 or 1");
-    VA_CHECK_ARG(p->tile_mask >= 0 && p->tile_mask < (1 << (kNumCfgs + 1)), "va_tvl1: tile_mask must be in [0, %d]", (1 << (kNumCfgs + 1)) - 1);
+    VA_CHECK_ARG(p->tile_mask >= 0 && p->tile_mask < (1 << (kNumCfgs + 2)), "va_tvl1: tile_mask must be in [0, %d]", (1 << (kNumCfgs + 2)) - 1);
+    VA_CHECK_ARG(p->rows_levels >= -1 && p->rows_levels < (1 << kMaxScales) && p->rows_cfg >= 0 && p->rows_cfg < 256,
+                 "va_tvl1: rows_levels must be -1 or a level bit set, rows_cfg in [0,255]");
     VA_CHECK_ARG(p->stream_levels >= -1 && p->stream_levels < (1 << kMaxScales) && (p->stream_waves == 0 || p->stream_waves == 1) &&
                      p->stream_chunks >= 0 && p->stream_slots >= 0,
                  "va_tvl1: stream_levels must be -1 or a level bit set, stream_waves 0 or 1, stream_chunks and stream_slots >= 0");
@@ -1184,7 +1680,7 @@ void make_plan(Plan& P, int w, int h, int n_seq, int fps, const va_tvl1_params* 
     P.NP = n_seq * (fps - 1);
     size_t off = 0;
     for (int s = 0; s < P.ns; ++s) {
-        P.pitch[s] = (P.ws[s] + 3) / 4 * 4;
+        P.pitch[s] = level_pitch(P.ws[s]);
         P.plane[s] = va_align_up((size_t)P.pitch[s] * P.hs[s], 64);
         P.off_pyr[s] = off;
         off += va_align_up((size_t)P.NF * 3 * P.plane[s] * sizeof(float), 256);
@@ -1237,6 +1733,8 @@ extern "C" void va_tvl1_default_params(va_tvl1_params* p)
     p->stream_waves = 0;
     p->stream_chunks = 0;
     p->stream_slots = 0;
+    p->rows_levels = -1;
+    p->rows_cfg = 0;
 }
 
 extern "C" int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* hs)
@@ -1258,8 +1756,15 @@ extern "C" int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out
         const unsigned tmask = (unsigned)p->tile_mask & (unsigned)(kStreamBit - 1);
         const TilePick tp = K0 > 0 ? pick_tiles(ws[s], hs[s], K0, tmask) : pick_tiles_auto(ws[s], hs[s], p->iters, tmask);
         const TileCfg& c = kCfgs[tp.cfg];
-        const int lp = (ws[s] + 3) / 4 * 4;
-        if (level_streams(p, p->epsilon > 0.0f, s, ws[s], hs[s], va_align_up((size_t)lp * hs[s], 64))) {
+        const int lp = level_pitch(ws[s]);
+        RowsPick rp{};
+        const int lk = level_kernel(p, p->epsilon > 0.0f, s, ws[s], hs[s], lp, va_align_up((size_t)lp * hs[s], 64), &rp);
+        if (lk == LK_ROWS) {
+            const int plan[6] = {64 * rp.ppl, 0, rp.nwv, rp.K, 1, 0};
+            memcpy(out + 6 * s, plan, sizeof(plan));
+            continue;
+        }
+        if (lk == LK_STREAM) {
             StreamPick sp{};
             stream_strips(p, ws[s], sp);
             const int plan[6] = {128, 0, sp.two ? 2 : 1, sp.HX, sp.nsx, 0};
@@ -1352,15 +1857,21 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
         const size_t plane = P.plane[s];
         const unsigned tmask = (unsigned)p->tile_mask & (unsigned)(kStreamBit - 1);
         const TilePick tp = K0 > 0 ? pick_tiles(lw, lh, K0, tmask) : pick_tiles_auto(lw, lh, p->iters, tmask);
-        const bool strm = level_streams(p, eps, s, lw, lh, plane);
-        const int perm = strm ? 0 : 1;
+        RowsPick rp{};
+        int lk = level_kernel(p, eps, s, lw, lh, lp, plane, &rp);
+        // k_iter_rows addresses both state buffers through one 32-bit buffer resource
+        const size_t st_lo = state[0] < state[1] ? 0 : 1;
+        const size_t st_span = (size_t)((char*)state[st_lo ^ 1] - (char*)state[st_lo]) + (size_t)kNF_STATE * plane * sizeof(float);
+        if (lk == LK_ROWS && st_span >= 2147483648ull) lk = level_streams(p, eps, s, lw, lh, plane) ? LK_STREAM : LK_TILE;
+        const bool strm = lk == LK_STREAM, rows = lk == LK_ROWS;
+        const int perm = (strm || rows) ? 0 : 1;
         if (lp != lw) {
             k_zero_pad<<<dim3(va_cdiv((lp - lw) * lh * kNF_RO, TPB), P.NP), TPB, 0, st>>>(ro, kNF_RO, lw, lh, lp, plane, perm);
             VA_LAUNCH_CHECK();
         }
         // the pairs of a level go through its warps x iterations in chunks (cache residency: chunk_pairs); every chunk
         // starts from the level's entry buffer index and ends on the same one
-        const int cp = (eps || !VA_CHUNK || strm) ? P.NP : chunk_pairs(lw, lh, tp, P.NP);
+        const int cp = (eps || !VA_CHUNK || strm || rows) ? P.NP : chunk_pairs(lw, lh, tp, P.NP);
         const int cur_in = cur;
         for (int c0 = 0; c0 < P.NP; c0 += cp) {
         const int nc = P.NP - c0 < cp ? P.NP - c0 : cp;
@@ -1399,6 +1910,32 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
             a.theta = p->theta;
             a.pair0 = c0;
             int launches = 0;
+            if (rows) {
+                RowsArgs ra{};
+                ra.ro = ro;
+                ra.st = state[st_lo];
+                ra.delta[st_lo] = 0u;
+                ra.delta[st_lo ^ 1] = (unsigned)((char*)state[st_lo ^ 1] - (char*)state[st_lo]);
+                ra.plane = plane;
+                ra.w = lw;
+                ra.h = lh;
+                ra.pitch = lp;
+                ra.K = rp.K;
+                ra.K0 = rp.K0;
+                ra.N = rp.N;
+                ra.cur = cur;
+                ra.pair0 = c0;
+                ra.l_t = a.l_t;
+                ra.taut = a.taut;
+                ra.theta = a.theta;
+                int rc;
+                if (rp.ppl == 2) rc = p->fast_math ? launch_rows<2, true>(rp, ra, nc, st) : launch_rows<2, false>(rp, ra, nc, st);
+                else if (rp.ppl == 3) rc = p->fast_math ? launch_rows<3, true>(rp, ra, nc, st) : launch_rows<3, false>(rp, ra, nc, st);
+                else rc = p->fast_math ? launch_rows<4, true>(rp, ra, nc, st) : launch_rows<4, false>(rp, ra, nc, st);
+                if (rc) return rc;
+                cur ^= rp.N & 1;
+                launches = 1;
+            }
             if (strm) {
                 const StreamPick sp = pick_stream(p, lw, lh, nc);
                 StreamArgs sa{};
@@ -1436,7 +1973,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                     ++launches;
                 }
             }
-            for (int it = strm ? p->iters : 0; it < p->iters;) {
+            for (int it = (strm || rows) ? p->iters : 0; it < p->iters;) {
                 // the tile grid depends on the halo depth: a shorter last launch gets its own grid
                 const int k = (p->iters - it) < tp.K ? (p->iters - it) : tp.K;
                 const TilePick tk = (k == tp.K) ? tp : pick_tiles(lw, lh, k, tmask);
@@ -1473,7 +2010,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
             const dim3 g(va_cdiv(P.ws[s - 1] * P.hs[s - 1], TPB), P.NP);
             k_upsample<<<g, TPB, 0, st>>>(state[0], state[1], eps ? sel : nullptr, cur, lw, lh, lp, plane, ro, P.ws[s - 1],
                                            P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1], 1.0f / p->scale_step, perm);
-            const int fperm = level_streams(p, eps, s - 1, P.ws[s - 1], P.hs[s - 1], P.plane[s - 1]) ? 0 : 1;
+            const int fperm = level_kernel(p, eps, s - 1, P.ws[s - 1], P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1], nullptr) != LK_TILE ? 0 : 1;
             const dim3 gi(va_cdiv(P.pitch[s - 1] * P.hs[s - 1], TPB), P.NP);
             k_level_init<<<gi, TPB, 0, st>>>(ro, state[0], P.ws[s - 1], P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1], fperm);
             VA_LAUNCH_CHECK();
@@ -1484,7 +2021,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
     {
         const dim3 g(va_cdiv(w * h, TPB), P.NP);
         k_flow_out<<<g, TPB, 0, st>>>(state[0], state[1], eps ? sel : nullptr, cur, w, h, P.pitch[0], P.plane[0], (float*)flow,
-                                       level_streams(p, eps, 0, w, h, P.plane[0]) ? 0 : 1);
+                                       level_kernel(p, eps, 0, w, h, P.pitch[0], P.plane[0], nullptr) != LK_TILE ? 0 : 1);
         VA_LAUNCH_CHECK();
     }
     return VA_OK;
