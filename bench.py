@@ -7,54 +7,103 @@ A "step" is one pass of the hot path over one batch of 32 synthetic clips per GP
 configs[1]: two-stream, 224x224, 10-frame flow stack, batch 32): 320 TV-L1 frame pairs in
 fixed-iteration mode (5 scales x 5 warps x 300 inner iterations), flow quantisation into the
 20-channel flow volume, the temporal and the spatial VGG-16 forward.  Inputs (u8 frames) and weights
-are resident in HBM before the timed region.  With N > 1 (launched by torch.distributed.run, one
-rank per GPU) every rank processes its own 32 clips per step (weak scaling) and the timed region
-ends with ONE RCCL all-gather of all per-clip class scores.
+are resident in HBM before the timed region.  Consecutive steps are software-pipelined on the device
+(batch i's flow quantisation + temporal CNN run beside batch i + 1's TV-L1; `--serial` turns that off); every
+step's work and results are complete inside the timed region.  With N > 1 every rank (one process per GPU:
+started by this script itself when it is run bare, or by torch.distributed.run) processes its own 32 clips per
+step (weak scaling) and the timed region ends with ONE RCCL all-gather of all per-clip class scores.
 
-Prints one JSON line (rank 0).  `roofline` is for the dominant kernel (the TV-L1 inner-iteration
-kernel): algorithmic bytes = 64 B per pixel-iteration, time measured live
-with HIP events around every run of its launches.  `cpu_baseline` times the CPU oracle (C TV-L1
-with OpenMP across pairs + torch-CPU VGG) on a bounded sample of the same workload.
+Prints one JSON line (rank 0).
+  roofline      the dominant kernels (TV-L1 inner iterations).  `achieved`/`frac` follow SURVEY.md section 8d:
+                64 algorithmic bytes per pixel-iteration / wall time the kernels run, measured live with HIP events
+                around every run of their launches.  Because the kernels fuse 10-16 iterations in registers, that figure
+                is NOT a bound they obey (it exceeds the HBM peak); it is repeated as `frac_algorithmic_64B`, and the
+                bounds they do obey are reported next to it: `hbm_measured` (PMC bytes of the committed profile of this
+                very tvl1.hip, or null) and `valu` (vector instructions per pixel-iteration from the committed
+                SQ counters against the issue capacity of 1024 SIMDs), plus `per_level` timings measured live.
+  roofline_cnn  the conv/FC stack: TFLOP/s of a CNN-only leg timed after the main region, against the MFMA peak.
+  cpu_baseline  the CPU oracle (C TV-L1 with OpenMP across pairs + torch-CPU VGG) on a bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense peaks (MI355X_MICROARCH.md)
+N_SIMD = 1024             # 256 CUs x 4 SIMDs
 BYTES_PER_PX_ITER = 64.0
 BYTES_PER_PX_WARP = 44.0
+GFLOP_PER_CLIP = 62.852   # two VGG-16 streams, SURVEY.md section 2a / 8d
 BATCH = 32
+TVL1_SRC = os.path.join(ROOT, "video_analytics_amd", "csrc", "tvl1.hip")
 
 
-def pmc_traffic_per_launch(block_iters, flow_streams):
-    """HBM bytes per inner-iteration launch (k_iter_stream, k_iter_tile) from the committed rocprofv3 PMC passes (profiles/rNN/
-    pmc_hbm_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command;
-    FETCH_SIZE doubled per the gfx950 rule of MI355X_MICROARCH.md, verified on this kernel's known
-    load count in profiles/README.md).  PMC cannot be collected inside a normal run: this reports the
-    profiled figure for the same configuration, or None if no profile matches it."""
+def git_blob_hash(path):
+    """What `git hash-object` prints for the file (no git needed on the GPU box)."""
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def committed_profile(name):
+    """profiles/rNN/<name> of the latest round whose `tvl1_hip_blob` stamp equals the current tvl1.hip: the counters
+    were collected on exactly these kernels.  None when the source has changed since (no stale figure is reported)."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm_summary.json")))
-    if not cands:
-        return None
-    try:
-        d = json.load(open(cands[-1]))
-        if int(d.get("block_iters", -1)) != block_iters or int(d.get("flow_streams", -1)) != flow_streams:
-            return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("tvl1_hip_blob") == git_blob_hash(TVL1_SRC):
+            d["_path"] = os.path.relpath(path, ROOT)
+            return d
+    return None
+
+
+def pmc_blocks(cfg, busy_ms_per_step, px_iters_per_step, launches_per_step):
+    """`traffic`, `hbm_measured` and `valu` from the committed PMC passes of this same command (separate rocprofv3
+    runs: FETCH_SIZE, WRITE_SIZE, SQ counters; FETCH_SIZE doubled per the gfx950 rule of MI355X_MICROARCH.md)."""
+    traffic = hbm = valu = None
+    d = committed_profile("pmc_hbm_summary.json")
+    if d and int(d.get("flow_streams", -1)) == cfg["flow_streams"] and int(d.get("block_iters", -1)) == cfg["block_iters"]:
         f = sum(v["sum_KB"] for k, v in d["FETCH_SIZE"].items() if k.startswith("k_iter"))
         w = sum(v["sum_KB"] for k, v in d["WRITE_SIZE"].items() if k.startswith("k_iter"))
         n = sum(v["launches"] for k, v in d["FETCH_SIZE"].items() if k.startswith("k_iter"))
-        return (2.0 * f + w) * 1024.0 / n
-    except Exception:
-        return None
+        steps = max(1, int(d.get("steps_profiled", 1)))
+        bytes_per_step = (2.0 * f + w) * 1024.0 / steps
+        traffic = (2.0 * f + w) * 1024.0 / n
+        gbs = bytes_per_step / (busy_ms_per_step * 1e-3) / 1e9
+        hbm = dict(GB_per_step=bytes_per_step / 1e9, GBps=gbs, frac_of_peak=gbs / HBM_PEAK_GBS,
+                   frac_of_algorithmic_bytes=bytes_per_step / (BYTES_PER_PX_ITER * px_iters_per_step), source=d["_path"])
+    v = committed_profile("pmc_valu_summary.json")
+    if v:
+        steps = max(1, int(v.get("steps_profiled", 1)))
+        insts = sum(x["SQ_INSTS_VALU"] for k, x in v["kernels"].items() if k.startswith("k_iter")) / steps
+        busy = sum(x["SQ_ACTIVE_INST_VALU"] for k, x in v["kernels"].items() if k.startswith("k_iter")) * 4.0 / steps  # quad-cycles
+        clock_ghz = float(v.get("clock_ghz", 2.3))
+        cap = N_SIMD * clock_ghz * 1e9 / 4.0  # wave-instructions per second the chip can issue (one per SIMD per 4 cycles)
+        valu = dict(wave_instr_per_px_iter=insts / px_iters_per_step, wave_instr_per_step=insts,
+                    issue_capacity_G_per_s=cap / 1e9, clock_ghz=clock_ghz,
+                    frac_useful=insts / cap / (busy_ms_per_step * 1e-3),
+                    frac_busy=busy / (N_SIMD * clock_ghz * 1e9) / (busy_ms_per_step * 1e-3),
+                    per_kernel={k: x["SQ_INSTS_VALU"] / max(x["px_iters"], 1.0) for k, x in v["kernels"].items()
+                                if k.startswith("k_iter") and x.get("px_iters")},
+                    source=v["_path"])
+    return traffic, hbm, valu
 
 
-def cpu_baseline(n_clips, tv_kw):
-    """CPU oracle on `n_clips` clips of the same workload: the checker, timed as a reported baseline."""
+def cpu_baseline(n_pairs_per_core, tv_kw, repeats=3):
+    """CPU oracle on a bounded sample of the same workload: the checker, timed as a reported baseline.  TV-L1: pairs =
+    a multiple of the threads used (every thread gets the same number of pairs), `repeats` timed runs after one warm-up,
+    median; CNN: both VGG-16 forwards of `cores` clips on torch-CPU, same protocol.  Combined: clips/s of a clip =
+    10 pairs + 2 forwards."""
+    import numpy as np
     import torch
     from oracle import tvl1_oracle, vgg_oracle
     from video_analytics_amd import synth
@@ -63,34 +112,46 @@ def cpu_baseline(n_clips, tv_kw):
     cores = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(cores)
     tvl1_oracle.build()
-    rgb, gray, _ = synth.synth_clips(n_clips, seed=0)
-    okw = dict(tv_kw)
-    P = tvl1_oracle.default_params(**okw)
-    t0 = time.time()
-    fl = tvl1_oracle.tvl1_flow(gray.numpy(), P, nthreads=cores)
-    st = tvl1_oracle.flow_to_stack(fl).reshape(n_clips, 20, 224, 224)
-    t_flow = time.time() - t0
+    n_pairs = cores * n_pairs_per_core
+    n_clips = -(-n_pairs // 10)
+    rgb, gray, _ = synth.synth_clips(max(n_clips, cores), seed=0)
+    # pairs (k, k+1) of consecutive gray frames, as sequences of 2 frames: exactly n_pairs of them
+    g = gray.numpy()
+    pairs = np.stack([g[i // 10, (i % 10):(i % 10) + 2] for i in range(n_pairs)])
+    P = tvl1_oracle.default_params(**tv_kw)
+    t_flow = []
+    for r in range(repeats + 1):
+        t0 = time.time()
+        tvl1_oracle.tvl1_flow(pairs if r else pairs[:cores], P, nthreads=cores)
+        if r:
+            t_flow.append(time.time() - t0)
     ws = synth.synth_vgg16_weights(c_in=3, seed=1)
     wt = synth.synth_vgg16_weights(c_in=20, seed=2)
     wt["conv_w"][0] = vgg_oracle.copy_first_layer(wt["conv_w"][0], 20)
-    xs = vgg_oracle.normalize_u8(rgb, NORM_MEANS_TF, NORM_STDS_TF)
-    xt = torch.from_numpy(st)
-    vgg_oracle.forward(xs[:1], ws["conv_w"], ws["conv_b"], ws["fc_w"], ws["fc_b"])  # warm-up
-    t0 = time.time()
-    vgg_oracle.forward(xs, ws["conv_w"], ws["conv_b"], ws["fc_w"], ws["fc_b"])
-    vgg_oracle.forward(xt, wt["conv_w"], wt["conv_b"], wt["fc_w"], wt["fc_b"])
-    t_cnn = time.time() - t0
-    return dict(value=n_clips / (t_flow + t_cnn), unit="clips/s", cores=cores, kind="port",
-                sample="%d clips (%d TV-L1 pairs 224x224 5x5x300 fixed iterations in the C oracle, OpenMP over pairs; "
-                       "two VGG-16 forwards on torch-CPU fp32): flow %.2f s, cnn %.2f s"
-                       % (n_clips, 10 * n_clips, t_flow, t_cnn))
+    xs = vgg_oracle.normalize_u8(rgb[:cores], NORM_MEANS_TF, NORM_STDS_TF)
+    xt = torch.from_numpy(synth.hash_uniform(9, 9, cores * 20 * 224 * 224).reshape(cores, 20, 224, 224) * 4.0 - 2.0)
+    t_cnn = []
+    for r in range(repeats + 1):
+        t0 = time.time()
+        vgg_oracle.forward(xs, ws["conv_w"], ws["conv_b"], ws["fc_w"], ws["fc_b"])
+        vgg_oracle.forward(xt, wt["conv_w"], wt["conv_b"], wt["fc_w"], wt["fc_b"])
+        if r:
+            t_cnn.append(time.time() - t0)
+    pairs_per_s = n_pairs / statistics.median(t_flow)
+    cnn_clips_per_s = cores / statistics.median(t_cnn)
+    value = 1.0 / (10.0 / pairs_per_s + 1.0 / cnn_clips_per_s)
+    return dict(value=value, unit="clips/s", cores=cores, kind="port", pairs_per_s=pairs_per_s, cnn_clips_per_s=cnn_clips_per_s,
+                repeats=repeats, flow_s=t_flow, cnn_s=t_cnn,
+                sample="%d TV-L1 pairs 224x224 5x5x300 fixed iterations in the C oracle (%d per thread, OpenMP over pairs), "
+                       "median of %d runs; two VGG-16 forwards of %d clips on torch-CPU fp32, median of %d; "
+                       "value = 1 / (10 / pairs_per_s + 1 / cnn_clips_per_s)" % (n_pairs, n_pairs_per_core, repeats, cores, repeats))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--block-iters", type=int, default=0, help="TV-L1 temporal blocking depth (0 = library default)")
     ap.add_argument("--tvl1-math", choices=["exact", "fast"], default="exact",
                     help="exact: bit-identical to the CPU oracle; fast: 1-ulp hardware sqrt/rcp (tolerance-tested)")
@@ -98,9 +159,16 @@ def main():
                     help="split the batch's TV-L1 work over this many HIP streams (their tile launches overlap)")
     ap.add_argument("--cnn-dtype", choices=["f32", "bf16"], default="f32",
                     help="f32: exact fp32 MFMA (headline, parity); bf16: BASELINE config 5 throughput mode")
-    ap.add_argument("--cpu-clips", type=int, default=2, help="clips in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-pairs-per-core", type=int, default=2,
+                    help="TV-L1 pairs per host thread in the CPU baseline sample (0 = skip the CPU leg)")
+    ap.add_argument("--cpu-clips", type=int, default=None, help="deprecated: 0 skips the CPU leg")
+    ap.add_argument("--serial", action="store_true",
+                    help="no overlap across batches: every step waits for its own results before the next one is enqueued")
     ap.add_argument("--no-flow", action="store_true", help="CNN only on precomputed flow volumes (not the headline metric)")
+    ap.add_argument("--tvl1-params", default="", help="name=value,... overrides of va_tvl1_params (experiments)")
     args = ap.parse_args()
+    if args.cpu_clips is not None and args.cpu_clips == 0:
+        args.cpu_pairs_per_core = 0
 
     from video_analytics_amd import launch
     if launch.needs_spawn(args.gpus):
@@ -127,7 +195,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     tv_kw = dict(epsilon=0.0, iters=300, warps=5, nscales=5)
-    params = _ffi.default_tvl1_params(block_iters=args.block_iters, fast_math=int(args.tvl1_math == "fast"), **tv_kw)
+    over = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tvl1_params.split(",") if kv}
+    params = _ffi.default_tvl1_params(block_iters=args.block_iters, fast_math=int(args.tvl1_math == "fast"), **tv_kw, **over)
     pipe = pipeline.TwoStreamPipeline(device=local_rank, tvl1_params=params, flow_streams=args.flow_streams,
                                       cnn_dtype=args.cnn_dtype)
     # distinct clips per rank: clip index = rank*BATCH + i
@@ -140,28 +209,38 @@ def main():
     K, Wm = args.steps, args.warmup
     scores = torch.zeros((max(K, 1) * BATCH, 2, 101), dtype=torch.float32, device=dev)
 
-    def step(i):
-        out = pipe.run_batch(rgb, gray, flow_stack=stack)
-        if i >= 0:
-            scores[i * BATCH:(i + 1) * BATCH, 0] = out["logits_s"]
-            scores[i * BATCH:(i + 1) * BATCH, 1] = out["logits_t"]
+    def run_steps(n, keep):
+        """n passes of the hot path, software-pipelined (pipeline.TwoStreamPipeline.submit: batch i's flow quantisation
+        and temporal CNN run beside batch i + 1's TV-L1); every pass is complete -- and its scores are in `scores` --
+        when this returns control to the timed region's closing synchronisation."""
+        outs = []
+        for _ in range(n):
+            outs.append(pipe.submit(rgb, gray, flow_stack=stack))
+            if args.serial:
+                pipe.wait()
+        pipe.wait()
+        if keep:
+            for i, out in enumerate(outs):
+                scores[i * BATCH:(i + 1) * BATCH, 0] = out["logits_s"]
+                scores[i * BATCH:(i + 1) * BATCH, 1] = out["logits_t"]
 
-    for _ in range(Wm):
-        step(-1)
+    run_steps(Wm, False)
     torch.cuda.synchronize()
     vflow.profile_enable(True, local_rank)
     vflow.profile_read(reset=True, device=local_rank)
+    vflow.profile_levels(16, reset=True, device=local_rank)
     vdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(K):
-        step(i)
+    run_steps(K, True)
     allscores = vdist.gather_scores(scores, world * K * BATCH, world) if world > 1 else scores
     torch.cuda.synchronize()
     vdist.barrier()
     t1 = time.perf_counter()
     elapsed = vdist.max_over_ranks(t1 - t0, dev)
-    prof = vflow.profile_read(reset=True, device=local_rank)
+    prof = vflow.profile_read(reset=False, device=local_rank)
+    levels = vflow.profile_levels(16, reset=True, device=local_rank)
+    vflow.profile_read(reset=True, device=local_rank)
     vflow.profile_enable(False, local_rank)
     assert allscores.shape[0] == world * K * BATCH
     ranks_seen = vdist.ranks_seen()
@@ -170,6 +249,7 @@ def main():
     if rank == 0:
         clips = world * K * BATCH
         value = clips / elapsed
+        cfg = dict(block_iters=args.block_iters, flow_streams=args.flow_streams)
         roof = None
         if prof["launches"] > 0 and prof["ms"] > 0:
             # `achieved`: algorithmic bytes of all inner-iteration launches / wall time during which they run
@@ -179,15 +259,40 @@ def main():
             alg_bytes = BYTES_PER_PX_ITER * prof["px_iters"]
             busy_ms = prof["union_ms"] if prof["union_ms"] > 0 else prof["ms"]
             ach = alg_bytes / (busy_ms * 1e-3) / 1e9
-            traffic = pmc_traffic_per_launch(args.block_iters, args.flow_streams)
+            traffic, hbm, valu = pmc_blocks(cfg, busy_ms / max(K, 1), prof["px_iters"] / max(K, 1), prof["launches"] / max(K, 1))
+            sizes = vflow.pyramid_sizes(224, 224, params)
+            per_level = [dict(level=s, w=sizes[s][0], h=sizes[s][1], ms_per_step=l["ms"] / max(K, 1),
+                              px_iters_per_step=l["px_iters"] / max(K, 1), launches_per_step=l["launches"] / max(K, 1),
+                              ns_per_kpx_iter=(l["ms"] * 1e6) / (l["px_iters"] / 1e3) if l["px_iters"] else None)
+                         for s, l in enumerate(levels[:len(sizes)])]
             roof = dict(bound="hbm", kernel="k_iter_stream + k_iter_tile (TV-L1 inner iterations)", achieved=ach, peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic,
+                        unit="GB/s", frac=ach / HBM_PEAK_GBS, frac_algorithmic_64B=ach / HBM_PEAK_GBS,
+                        note="frac is the SURVEY 8d figure (64 algorithmic B per pixel-iteration); the kernels fuse 10-16 "
+                             "iterations in registers, so it is not an efficiency: see hbm_measured and valu",
+                        traffic=traffic, hbm_measured=hbm, valu=valu, per_level=per_level,
                         launches=int(prof["launches"]), avg_launch_us=prof["ms"] * 1e3 / prof["launches"],
                         alg_bytes_per_launch=alg_bytes / prof["launches"], kernel_ms_per_step=busy_ms / max(K, 1),
                         achieved_per_launch=alg_bytes / (prof["ms"] * 1e-3) / 1e9, concurrent_streams=args.flow_streams)
+        # CNN-only leg (outside the timed region): both VGG-16 streams on precomputed flow volumes
+        cnn = None
+        if world == 1:
+            st2 = stack if stack is not None else pipe.flow_volume(gray)
+            pipe.run_batch(rgb, flow_stack=st2)
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            for _ in range(5):
+                pipe.submit(rgb, flow_stack=st2)
+            pipe.wait()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - tc) / 5 * 1e3
+            tf = BATCH * GFLOP_PER_CLIP / ms  # GFLOP / ms = TFLOP/s
+            peak = MFMA_PEAK_TFLOPS[args.cnn_dtype]
+            cnn = dict(bound="mfma", kernel="k_conv3x3_* + k_fc_* (both VGG-16 streams, 32 clips)", achieved=tf, peak=peak,
+                       unit="TFLOP/s", frac=tf / peak, ms_per_batch=ms, gflop_per_clip=GFLOP_PER_CLIP, dtype=args.cnn_dtype,
+                       note="whole CNN leg incl. layout, FC and launch gaps; counter-based MFMA utilisation per layer: profiles/")
         cpu = None
-        if world == 1 and args.cpu_clips > 0:
-            cpu = cpu_baseline(args.cpu_clips, tv_kw)
+        if world == 1 and args.cpu_pairs_per_core > 0:
+            cpu = cpu_baseline(args.cpu_pairs_per_core, tv_kw)
         line = {
             "metric": "clips/sec (224x224, RGB+10-flow two-stream)",
             "value": value, "unit": "clips/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": K, "warmup": Wm,
@@ -195,9 +300,10 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.cnn_dtype == "f32" else "bf16 (CNN) / f32 (TV-L1)", "data": "synthetic",
             "config": {"workload": "two-stream 224x224, 10-frame TV-L1 flow stack (5 scales x 5 warps x 300 its, fixed), "
                                    "VGG-16 spatial+temporal, batch=32 per GPU" + (" [CNN only: --no-flow]" if args.no_flow else ""),
-                       "global_batch": world * BATCH, "block_iters": args.block_iters, "tvl1_math": args.tvl1_math, "flow_streams": args.flow_streams, "parallelism": "clips sharded x%d" % world,
-                       "finite": finite},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "global_batch": world * BATCH, "block_iters": args.block_iters, "tvl1_math": args.tvl1_math,
+                       "flow_streams": args.flow_streams, "batches_in_flight": 1 if args.serial else 2,
+                       "tvl1_hip_blob": git_blob_hash(TVL1_SRC), "parallelism": "clips sharded x%d" % world, "finite": finite},
+            "roofline": roof, "roofline_cnn": cnn, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     pipe.close()

@@ -224,6 +224,10 @@ int va_selftest_exact_math(va_ctx* ctx, float lo, float hi, unsigned long long* 
  */
 int va_tvl1_profile_enable(va_ctx* ctx, int on);
 int va_tvl1_profile_read(va_ctx* ctx, double* out, int reset);
+/* The same measurement per pyramid level (0 = full resolution): out[3*s + 0] = summed per-call milliseconds of the
+ * level's inner-iteration launches, out[3*s + 1] = its pixel-iterations, out[3*s + 2] = its launches (HOST array of
+ * 3*n doubles, n <= 16).  Call va_tvl1_profile_read(reset = 0) first (it synchronises the events), then this. */
+int va_tvl1_profile_levels(va_ctx* ctx, double* out, int n, int reset);
 
 /* ------------------------------------------------ video-level aggregation and fusion --- */
 

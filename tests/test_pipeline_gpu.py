@@ -169,6 +169,37 @@ def test_sharded_sweep_equals_single_batch_results():
     pipe.close()
 
 
+def test_pipelined_batches_equal_unpipelined_results():
+    """TwoStreamPipeline.submit() overlaps batch i's flow quantisation + temporal CNN with batch i + 1's TV-L1 (separate
+    streams, pipeline-owned double buffers guarded by events).  Five different batches submitted back to back (more
+    than the buffer depth, ragged last batch) must give exactly what run_batch gives one batch at a time -- also with
+    a single TV-L1 stream and with a buffer depth of 1."""
+    from video_analytics_amd import _ffi, pipeline, synth
+    kw = dict(epsilon=0.0, iters=25, warps=2, nscales=3)
+    dev = torch.device("cuda", 0)
+    sizes = [8, 8, 8, 8, 5]
+    batches = []
+    for i, n in enumerate(sizes):
+        rgb, gray, _ = synth.synth_clips(n, seed=20, first_clip=8 * i, device=dev)
+        batches.append((rgb, gray))
+    pipe = pipeline.TwoStreamPipeline(device=0, tvl1_params=_ffi.default_tvl1_params(**kw))
+    ref = []
+    for rgb, gray in batches:
+        r = pipe.run_batch(rgb, gray)
+        ref.append({k: r[k].clone() for k in ("logits_s", "logits_t", "desc_s", "desc_t")})
+    torch.cuda.synchronize()
+    for streams, depth in ((2, 2), (1, 2), (2, 1), (3, 3)):
+        p2 = pipeline.TwoStreamPipeline(device=0, tvl1_params=_ffi.default_tvl1_params(**kw), flow_streams=streams, depth=depth)
+        outs = [p2.submit(rgb, gray) for rgb, gray in batches]
+        p2.wait()
+        torch.cuda.synchronize()
+        for o, r in zip(outs, ref):
+            for k in r:
+                assert torch.equal(o[k], r[k]), (streams, depth, k)
+        p2.close()
+    pipe.close()
+
+
 def test_config1_demoTest_clip_through_dataset_and_validate(tmp_path):
     """BASELINE config 1 end to end: the first lines of the reference's own Sheet03/demoTest.txt -> SpatialDataset over
     a frame directory in the reference's layout (<root>/<category>/<video>/<i>.jpg, Sheet03/spatialModel.py:64-81:

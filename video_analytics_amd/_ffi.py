@@ -19,7 +19,7 @@ EXPORTS = [
     "va_vgg16_create", "va_vgg16_destroy", "va_vgg16_workspace_bytes", "va_vgg16_set_option", "va_vgg16_forward", "va_vgg16_classify",
     "va_copy_first_layer", "va_validate_batch",
     "va_tvl1_default_params", "va_tvl1_pyramid_sizes", "va_tvl1_tile_plan", "va_tvl1_workspace_bytes", "va_tvl1_flow",
-    "va_flow_to_stack", "va_selftest_exact_math", "va_tvl1_profile_enable", "va_tvl1_profile_read",
+    "va_flow_to_stack", "va_selftest_exact_math", "va_tvl1_profile_enable", "va_tvl1_profile_read", "va_tvl1_profile_levels",
     "va_meter_update", "va_meter_average", "va_linear_svm_predict",
     "va_vgg16_train_init", "va_vgg16_train_workspace_bytes", "va_vgg16_train_step",
     "va_vgg16_export_state", "va_vgg16_import_state", "va_vgg16_train_plan",
@@ -112,6 +112,8 @@ def lib():
     L.va_tvl1_profile_enable.restype = ci
     L.va_tvl1_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ci]
     L.va_tvl1_profile_read.restype = ci
+    L.va_tvl1_profile_levels.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ci, ci]
+    L.va_tvl1_profile_levels.restype = ci
     L.va_meter_update.argtypes = [vp, vp, vp, ci, ci, vp, vp, ci, vp]
     L.va_meter_update.restype = ci
     L.va_meter_average.argtypes = [vp, vp, vp, ci, ci, vp, vp]

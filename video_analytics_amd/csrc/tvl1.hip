@@ -1885,6 +1885,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
             va_prof_span span{};
             if (ctx->prof_on) {
                 span = prof_get(ctx);
+                span.level = s;
                 VA_HIP(hipEventRecord(span.beg, st));
             }
             IterArgs a{};
@@ -2002,6 +2003,10 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                 ctx->prof_launches += launches;
                 ctx->prof_pxiters += (double)nc * lw * lh * p->iters;
                 ctx->prof_pxwarps += (double)nc * lw * lh;
+                if (s < kVaProfLevels) {
+                    ctx->prof_level_pxiters[s] += (double)nc * lw * lh * p->iters;
+                    ctx->prof_level_launches[s] += launches;
+                }
             }
         }
         }
@@ -2080,6 +2085,7 @@ extern "C" int va_tvl1_profile_read(va_ctx* ctx, double* out, int reset)
         float ms = 0.0f, t0 = 0.0f, t1 = 0.0f;
         VA_HIP(hipEventElapsedTime(&ms, s.beg, s.end));
         ctx->prof_ms += ms;
+        if (s.level >= 0 && s.level < kVaProfLevels) ctx->prof_level_ms[s.level] += ms;
         if (ctx->prof_ref) {
             VA_HIP(hipEventElapsedTime(&t0, ctx->prof_ref, s.beg));
             VA_HIP(hipEventElapsedTime(&t1, ctx->prof_ref, s.end));
@@ -2107,5 +2113,21 @@ extern "C" int va_tvl1_profile_read(va_ctx* ctx, double* out, int reset)
     out[3] = ctx->prof_pxwarps;
     out[4] = ctx->prof_union_ms;
     if (reset) ctx->prof_ms = ctx->prof_union_ms = ctx->prof_launches = ctx->prof_pxiters = ctx->prof_pxwarps = 0.0;
+    return VA_OK;
+}
+
+// Per pyramid level (0 = full resolution), since the last reset: out[3*s + 0] = summed per-call milliseconds of the
+// level's inner-iteration launches, out[3*s + 1] = pixel-iterations, out[3*s + 2] = launches (HOST array of 3*n
+// doubles, n <= 16).  Call after va_tvl1_profile_read (which synchronises the events) and before its reset.
+extern "C" int va_tvl1_profile_levels(va_ctx* ctx, double* out, int n, int reset)
+{
+    VA_CHECK_ARG(ctx != nullptr && out != nullptr && n >= 1 && n <= kVaProfLevels, "va_tvl1_profile_levels: bad argument");
+    for (int s = 0; s < n; ++s) {
+        out[3 * s + 0] = ctx->prof_level_ms[s];
+        out[3 * s + 1] = ctx->prof_level_pxiters[s];
+        out[3 * s + 2] = ctx->prof_level_launches[s];
+    }
+    if (reset)
+        for (int s = 0; s < kVaProfLevels; ++s) ctx->prof_level_ms[s] = ctx->prof_level_pxiters[s] = ctx->prof_level_launches[s] = 0.0;
     return VA_OK;
 }

@@ -36,6 +36,7 @@ extern "C" int va_ctx_create(int device, va_ctx** out)
     c->prof_on = false;
     c->prof_ref = nullptr;
     c->prof_ms = c->prof_union_ms = c->prof_launches = c->prof_pxiters = c->prof_pxwarps = 0.0;
+    for (int i = 0; i < kVaProfLevels; ++i) c->prof_level_ms[i] = c->prof_level_pxiters[i] = c->prof_level_launches[i] = 0.0;
     *out = c;
     return VA_OK;
 }

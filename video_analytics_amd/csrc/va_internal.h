@@ -8,7 +8,9 @@
 
 struct va_prof_span {
     hipEvent_t beg, end;
+    int level;  // pyramid level the bracketed inner-iteration launches belong to
 };
+constexpr int kVaProfLevels = 16;
 
 struct va_ctx {
     int device;
@@ -19,6 +21,7 @@ struct va_ctx {
     std::vector<va_prof_span> prof_pool;   // reusable events
     hipEvent_t prof_ref;                   // time origin for the union of spans (several streams)
     double prof_ms, prof_union_ms, prof_launches, prof_pxiters, prof_pxwarps;
+    double prof_level_ms[kVaProfLevels], prof_level_pxiters[kVaProfLevels], prof_level_launches[kVaProfLevels];
 };
 
 void va_set_error(const char* fmt, ...);

@@ -69,39 +69,67 @@ def tvl1_flow(frames, params=None, ws_slot=0, out=None, **over):
 _streams = {}
 
 
-def tvl1_flow_concurrent(frames, params=None, n_streams=2):
+def flow_streams(device, n):
+    """The ``n`` HIGH-priority HIP streams TV-L1 calls are spread over on ``device`` (created once): their launches
+    are dispatched ahead of whatever runs beside them (the CNN stream of pipeline.py has normal priority)."""
+    key = (device.index, n)
+    if key not in _streams:
+        _streams[key] = [torch.cuda.Stream(device=device, priority=-1) for _ in range(n)]
+    return _streams[key]
+
+
+def tvl1_flow_concurrent(frames, params=None, n_streams=2, out=None, after=None, join=True):
     """Same result as ``tvl1_flow`` for ``[S,F,H,W]`` frames, with the sequences split into ``n_streams``
     groups that run on separate HIP streams (each with its own workspace).  Kernels of the groups
     then overlap on the GPU: the un-overlapped HBM round trips and partial last rounds of one
-    group's tile launches are filled by the other's (measured +10 % at 320 pairs)."""
+    group's tile launches are filled by the other's (measured +10 % at 320 pairs).
+
+    ``after``: a CUDA event (or a list of events) the group streams wait for instead of the current stream (the frames -- and ``out`` --
+    are ready when it fires).  ``join=False``: the current stream does NOT wait for the groups; the call returns
+    ``(flow, events)`` with one event per group stream (pipeline.py chains the consumer on them, so that the next
+    batch's TV-L1 can be enqueued behind this one without waiting for this batch's consumers)."""
     if frames.dim() != 4:
         raise ValueError("tvl1_flow_concurrent: frames must be [S,F,H,W]")
     S = frames.shape[0]
     n = max(1, min(int(n_streams), S))
-    if n == 1:
-        return tvl1_flow(frames, params)
     dev = frames.device
-    key = (dev.index, n)
-    if key not in _streams:
-        # high priority: their tile launches are dispatched ahead of anything that runs beside them (pipeline.py)
-        _streams[key] = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(n)]
+    F = frames.shape[1]
+    if n == 1 and after is None and join:
+        return tvl1_flow(frames, params, out=out)
+    streams = flow_streams(dev, n)
     cur = torch.cuda.current_stream(dev)
     bounds = [(S * i) // n for i in range(n + 1)]
-    F = frames.shape[1]
-    flow = torch.empty((S * (F - 1), 2, frames.shape[2], frames.shape[3]), dtype=torch.float32, device=dev)
-    for i, st in enumerate(_streams[key]):
-        st.wait_stream(cur)
+    if out is None:
+        flow = torch.empty((S * (F - 1), 2, frames.shape[2], frames.shape[3]), dtype=torch.float32, device=dev)
+    else:
+        flow = out
+        if tuple(flow.shape) != (S * (F - 1), 2, frames.shape[2], frames.shape[3]) or flow.dtype != torch.float32 or not flow.is_contiguous():
+            raise ValueError("tvl1_flow_concurrent: out must be a contiguous float32 [%d,2,%d,%d] tensor" % (S * (F - 1), frames.shape[2], frames.shape[3]))
+    events = []
+    for i, st in enumerate(streams):
+        if after is None:
+            st.wait_stream(cur)
+        else:
+            for ev in (after if isinstance(after, (list, tuple)) else [after]):
+                if ev is not None:
+                    st.wait_event(ev)
         with torch.cuda.stream(st):
             part = frames[bounds[i]:bounds[i + 1]]
             part.record_stream(st)
             flow.record_stream(st)
             tvl1_flow(part, params, ws_slot=i + 1, out=flow[bounds[i] * (F - 1):bounds[i + 1] * (F - 1)])
-    for st in _streams[key]:
+            if not join:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                events.append(ev)
+    if not join:
+        return flow, events
+    for st in streams:
         cur.wait_stream(st)
     return flow
 
 
-def flow_to_stack(flow, bound=FLOW_BOUND, mean=NORM_MEANS_TF[0], std=NORM_STDS_TF[0]):
+def flow_to_stack(flow, bound=FLOW_BOUND, mean=NORM_MEANS_TF[0], std=NORM_STDS_TF[0], out=None):
     """flow ``[N,2,H,W]`` float32 -> ``[2N,H,W]`` float32 flow volume: 8-bit quantisation, ToTensor,
     Normalize with the single-channel rule (mean 0.485 / std 0.229: Sheet03/utils.py:148-150,
     SURVEY.md a5), channels interleaved x,y (Sheet03/temporalModel.py:83)."""
@@ -111,7 +139,10 @@ def flow_to_stack(flow, bound=FLOW_BOUND, mean=NORM_MEANS_TF[0], std=NORM_STDS_T
         raise ValueError("flow_to_stack: flow must be [N,2,H,W]")
     flow = flow.contiguous()
     N, _, H, W = flow.shape
-    out = torch.empty((2 * N, H, W), dtype=torch.float32, device=flow.device)
+    if out is None:
+        out = torch.empty((2 * N, H, W), dtype=torch.float32, device=flow.device)
+    elif out.numel() != 2 * N * H * W or out.dtype != torch.float32 or not out.is_contiguous() or out.device != flow.device:
+        raise ValueError("flow_to_stack: out must be a contiguous float32 tensor of %d elements on the flow's device" % (2 * N * H * W))
     _ffi.check(_ffi.lib().va_flow_to_stack(_ffi.ctx(flow.device.index), _ffi.ptr(flow), N, W, H, float(bound),
                                            float(mean), float(std), _ffi.ptr(out), _ffi.stream_ptr(flow.device)))
     return out
@@ -137,6 +168,14 @@ def tile_plan(w, h, params=None):
 
 def profile_enable(on=True, device=None):
     _ffi.check(_ffi.lib().va_tvl1_profile_enable(_ffi.ctx(device), int(bool(on))))
+
+
+def profile_levels(n_levels, reset=True, device=None):
+    """Per pyramid level since the last reset: list of dict(ms, px_iters, launches) (call ``profile_read(reset=False)``
+    first: it synchronises the recorded events)."""
+    out = (ctypes.c_double * (3 * n_levels))()
+    _ffi.check(_ffi.lib().va_tvl1_profile_levels(_ffi.ctx(device), out, n_levels, int(bool(reset))))
+    return [dict(ms=out[3 * s], px_iters=out[3 * s + 1], launches=out[3 * s + 2]) for s in range(n_levels)]
 
 
 def profile_read(reset=True, device=None):

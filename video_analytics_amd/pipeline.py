@@ -24,8 +24,21 @@ def build_stream_weights(c_in, seed, device):
 
 
 class TwoStreamPipeline(object):
+    """Batches flow through three sets of HIP streams:
+
+      * TV-L1 of a batch on ``flow_streams`` HIGH-priority streams (its pairs split between them),
+      * both CNN forwards, the flow quantisation and the outputs on ONE normal-priority stream (``cnn``): its kernels
+        get the CUs the TV-L1 launches leave idle (the tails of their ~2000 launches per batch),
+      * the caller's stream only records "inputs ready" and, when it wants the results, waits for the CNN stream.
+
+    ``submit()`` enqueues a batch and returns at once; the TV-L1 launches of batch i + 1 queue directly behind those of
+    batch i, so batch i's flow quantisation and temporal CNN (which can only start when its last flow is done) run
+    beside batch i + 1's TV-L1 instead of holding the TV-L1 streams idle (12 ms of a 140 ms step in round 1).
+    ``run_batch()`` = ``submit()`` + ``wait()``: the unpipelined form, same results bit for bit.
+    Buffers that cross streams (flow, flow volume) are owned by the pipeline, ``depth`` of each, guarded by events."""
+
     def __init__(self, device=None, spatial_seed=1, temporal_seed=2, flow_count=VIDEO_INPUT_FLOW_COUNT,
-                 tvl1_params=None, weights=None, flow_streams=2, cnn_dtype="f32"):
+                 tvl1_params=None, weights=None, flow_streams=2, cnn_dtype="f32", depth=2):
         dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.device = dev
         self.L = flow_count
@@ -38,14 +51,17 @@ class TwoStreamPipeline(object):
             self.temporal = vgg.Vgg16Stream(wt["conv_w"], wt["conv_b"], wt["fc_w"], wt["fc_b"], NACTION_CLASSES,
                                             VIDEO_DESCRIPTOR_DIM, device=dev.index, dtype=cnn_dtype)
         self.tvl1_params = tvl1_params
-        self.flow_streams = flow_streams
-        # The spatial CNN runs on a normal-priority side stream beside the HIGH-priority TV-L1 streams: its
-        # workgroups only get the CUs the tile launches leave idle (tails of launches).  Measured +1 % clips/s;
-        # at equal priority it delayed the tile launches (-5 %).
-        self._side = torch.cuda.Stream(device=dev, priority=0) if flow_streams > 1 else None
+        self.flow_streams = max(1, int(flow_streams))
+        self.depth = max(1, int(depth))
+        self._cnn = torch.cuda.Stream(device=dev, priority=0)
+        self._n = 0
+        self._flow = [None] * self.depth      # per slot: flow [pairs,2,H,W] written by the TV-L1 streams
+        self._stack = [None] * self.depth     # per slot: flow volume read by the temporal CNN
+        self._flow_read = [None] * self.depth  # per slot: event "the flow buffer has been quantised" (it may be overwritten)
+        self._handed_out = []                 # output tensors allocated on the CNN stream since the last wait()
 
     def flow_volume(self, gray):
-        """gray u8/f32 ``[B, L+1, 224, 224]`` -> flow volume f32 ``[B, 2L, 224, 224]``."""
+        """gray u8/f32 ``[B, L+1, 224, 224]`` -> flow volume f32 ``[B, 2L, 224, 224]`` (ordered on the current stream)."""
         B, F, H, W = gray.shape
         if F != self.L + 1:
             raise ValueError("flow_volume: need %d gray frames per clip, got %d" % (self.L + 1, F))
@@ -55,27 +71,69 @@ class TwoStreamPipeline(object):
             fl = vflow.tvl1_flow(gray, self.tvl1_params)
         return vflow.flow_to_stack(fl).view(B, 2 * self.L, H, W)
 
-    def run_batch(self, rgb, gray=None, flow_stack=None):
-        """-> dict(logits_s, logits_t, desc_s, desc_t).  ``flow_stack`` (precomputed volumes, the
-        reference's actual input) skips TV-L1."""
-        if flow_stack is not None or self._side is None:
+    def _buffer(self, bank, k, shape):
+        t = bank[k]
+        if t is None or tuple(t.shape) != tuple(shape):
+            bank[k] = t = torch.empty(shape, dtype=torch.float32, device=self.device)
+        return t
+
+    def submit(self, rgb, gray=None, flow_stack=None):
+        """Enqueue one batch; -> dict(logits_s, logits_t, desc_s, desc_t, done) of tensors that the CNN stream is still
+        writing (``done``: the event recorded behind them): call ``wait()`` (or ``run_batch``) before reading them
+        on another stream.  ``flow_stack``
+        (precomputed volumes, the reference's actual input) skips TV-L1."""
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(cur)  # the inputs are complete here; nothing below makes `cur` wait for anything
+        k = self._n % self.depth
+        self._n += 1
+        flow = evs = None
+        if flow_stack is None:
+            B, F, H, W = gray.shape
+            if F != self.L + 1:
+                raise ValueError("submit: need %d gray frames per clip, got %d" % (self.L + 1, F))
+            fbuf = self._buffer(self._flow, k, (B * self.L, 2, H, W))
+            flow, evs = vflow.tvl1_flow_concurrent(gray, self.tvl1_params, self.flow_streams, out=fbuf,
+                                                   after=[ready, self._flow_read[k]], join=False)
+        with torch.cuda.stream(self._cnn):
+            self._cnn.wait_event(ready)
+            rgb.record_stream(self._cnn)
             _, desc_s, logits_s = self.spatial.forward(rgb)
             if flow_stack is None:
-                flow_stack = self.flow_volume(gray)
-            _, desc_t, logits_t = self.temporal.forward(flow_stack)
-            return dict(logits_s=logits_s, logits_t=logits_t, desc_s=desc_s, desc_t=desc_t)
-        cur = torch.cuda.current_stream(self.device)
-        self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side):
-            rgb.record_stream(self._side)
-            _, desc_s, logits_s = self.spatial.forward(rgb)
-        flow_stack = self.flow_volume(gray)
-        _, desc_t, logits_t = self.temporal.forward(flow_stack)
-        cur.wait_stream(self._side)
-        for t in (desc_s, logits_s):
-            t.record_stream(cur)
-        return dict(logits_s=logits_s, logits_t=logits_t, desc_s=desc_s, desc_t=desc_t)
+                for ev in evs:
+                    self._cnn.wait_event(ev)
+                B, F, H, W = gray.shape
+                stack = vflow.flow_to_stack(flow, out=self._buffer(self._stack, k, (B, 2 * self.L, H, W)))
+                done = torch.cuda.Event()
+                done.record(self._cnn)
+                self._flow_read[k] = done
+            else:
+                flow_stack.record_stream(self._cnn)
+                stack = flow_stack
+            _, desc_t, logits_t = self.temporal.forward(stack)
+            finished = torch.cuda.Event()
+            finished.record(self._cnn)
+        out = dict(logits_s=logits_s, logits_t=logits_t, desc_s=desc_s, desc_t=desc_t)
+        self._handed_out.extend(out.values())
+        out["done"] = finished  # host-side throttle: out["done"].synchronize() blocks the HOST until this batch is complete
+        return out
+
+    def wait(self, stream=None):
+        """Make ``stream`` (default: the current one) wait for every batch submitted so far."""
+        s = torch.cuda.current_stream(self.device) if stream is None else stream
+        s.wait_stream(self._cnn)
+        for t in self._handed_out:
+            t.record_stream(s)
+        self._handed_out = []
+
+    def run_batch(self, rgb, gray=None, flow_stack=None):
+        """-> dict(logits_s, logits_t, desc_s, desc_t), ready on the current stream (``submit`` + ``wait``)."""
+        out = self.submit(rgb, gray, flow_stack)
+        self.wait()
+        return out
 
     def close(self):
+        self._cnn.synchronize()
         self.spatial.close()
         self.temporal.close()

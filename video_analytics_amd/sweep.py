@@ -10,23 +10,27 @@ import torch
 from . import dist as vdist
 
 
+MAX_IN_FLIGHT = 4  # batches the host may run ahead of the device
+
+
 def run_sweep(pipe, n_clips, make_batch, batch_size=32, rank=0, world=1):
     """``make_batch(lo, hi) -> (rgb u8 [n,3,224,224], gray u8 [n,L+1,224,224])`` on ``pipe.device`` for the
     global clip indices [lo, hi).  Returns scores ``[n_clips, 2, nClasses]`` (0 = spatial, 1 = temporal)
     on every rank, in global clip order."""
     lo, hi = vdist.shard_range(n_clips, rank, world)
     n_local = hi - lo
-    out = None
+    pending = []
     for b0 in range(lo, hi, batch_size):
         b1 = min(hi, b0 + batch_size)
         rgb, gray = make_batch(b0, b1)
-        r = pipe.run_batch(rgb, gray)
-        if out is None:
-            out = torch.empty((n_local, 2, r["logits_s"].shape[1]), dtype=torch.float32, device=r["logits_s"].device)
+        pending.append((b0, b1, pipe.submit(rgb, gray)))  # batches overlap: see TwoStreamPipeline
+        if len(pending) > MAX_IN_FLIGHT:  # the HOST waits (the device queues stay full): bounds the inputs kept alive
+            pending[-1 - MAX_IN_FLIGHT][2]["done"].synchronize()
+    pipe.wait()
+    out = torch.empty((n_local, 2, pipe.spatial.n_classes), dtype=torch.float32, device=pipe.device)
+    for b0, b1, r in pending:
         out[b0 - lo:b1 - lo, 0] = r["logits_s"]
         out[b0 - lo:b1 - lo, 1] = r["logits_t"]
-    if out is None:
-        out = torch.empty((0, 2, pipe.spatial.n_classes), dtype=torch.float32, device=pipe.device)
     return vdist.gather_scores(out, n_clips, world)
 
 
