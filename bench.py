@@ -7,9 +7,9 @@ A "step" is one pass of the hot path over one batch of 32 synthetic clips per GP
 configs[1]: two-stream, 224x224, 10-frame flow stack, batch 32): 320 TV-L1 frame pairs in
 fixed-iteration mode (5 scales x 5 warps x 300 inner iterations), flow quantisation into the
 20-channel flow volume, the temporal and the spatial VGG-16 forward.  Inputs (u8 frames) and weights
-are resident in HBM before the timed region.  Consecutive steps are software-pipelined on the device
-(batch i's flow quantisation + temporal CNN run beside batch i + 1's TV-L1; `--serial` turns that off); every
-step's work and results are complete inside the timed region.  With N > 1 every rank (one process per GPU:
+are resident in HBM before the timed region.  Inside a step the spatial CNN runs beside TV-L1 on its own stream;
+`--pipelined` additionally overlaps consecutive steps (measured slower, see the flag); either way every step's work
+and results are complete inside the timed region.  With N > 1 every rank (one process per GPU:
 started by this script itself when it is run bare, or by torch.distributed.run) processes its own 32 clips per
 step (weak scaling) and the timed region ends with ONE RCCL all-gather of all per-clip class scores.
 
@@ -162,8 +162,10 @@ def main():
     ap.add_argument("--cpu-pairs-per-core", type=int, default=2,
                     help="TV-L1 pairs per host thread in the CPU baseline sample (0 = skip the CPU leg)")
     ap.add_argument("--cpu-clips", type=int, default=None, help="deprecated: 0 skips the CPU leg")
-    ap.add_argument("--serial", action="store_true",
-                    help="no overlap across batches: every step waits for its own results before the next one is enqueued")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="enqueue batch i + 1 before batch i's results are waited for (its flow quantisation + temporal CNN then "
+                         "run beside batch i + 1's TV-L1).  Measured SLOWER (216 vs 226 clips/s): the GPU is saturated, the "
+                         "CNN has no idle CUs to hide in, and low-priority fragments disturb the two TV-L1 streams")
     ap.add_argument("--no-flow", action="store_true", help="CNN only on precomputed flow volumes (not the headline metric)")
     ap.add_argument("--tvl1-params", default="", help="name=value,... overrides of va_tvl1_params (experiments)")
     args = ap.parse_args()
@@ -210,13 +212,12 @@ def main():
     scores = torch.zeros((max(K, 1) * BATCH, 2, 101), dtype=torch.float32, device=dev)
 
     def run_steps(n, keep):
-        """n passes of the hot path, software-pipelined (pipeline.TwoStreamPipeline.submit: batch i's flow quantisation
-        and temporal CNN run beside batch i + 1's TV-L1); every pass is complete -- and its scores are in `scores` --
-        when this returns control to the timed region's closing synchronisation."""
+        """n passes of the hot path; every pass is complete -- and its scores are in `scores` -- when this returns
+        control to the timed region's closing synchronisation."""
         outs = []
         for _ in range(n):
             outs.append(pipe.submit(rgb, gray, flow_stack=stack))
-            if args.serial:
+            if not args.pipelined:
                 pipe.wait()
         pipe.wait()
         if keep:
@@ -301,7 +302,7 @@ def main():
             "config": {"workload": "two-stream 224x224, 10-frame TV-L1 flow stack (5 scales x 5 warps x 300 its, fixed), "
                                    "VGG-16 spatial+temporal, batch=32 per GPU" + (" [CNN only: --no-flow]" if args.no_flow else ""),
                        "global_batch": world * BATCH, "block_iters": args.block_iters, "tvl1_math": args.tvl1_math,
-                       "flow_streams": args.flow_streams, "batches_in_flight": 1 if args.serial else 2,
+                       "flow_streams": args.flow_streams, "batches_in_flight": 2 if args.pipelined else 1,
                        "tvl1_hip_blob": git_blob_hash(TVL1_SRC), "parallelism": "clips sharded x%d" % world, "finite": finite},
             "roofline": roof, "roofline_cnn": cnn, "cpu_baseline": cpu,
         }

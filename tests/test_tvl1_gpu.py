@@ -19,7 +19,7 @@ def _frames(n_seq, n_frames, H, W, seed):
 
 
 # tuning fields of va_tvl1_params the oracle has no counterpart for (results must not depend on them)
-PRODUCT_ONLY = ("block_iters", "tile_mask", "stream_levels", "stream_waves", "stream_chunks", "stream_slots", "rows_levels", "rows_cfg")
+PRODUCT_ONLY = ("block_iters", "tile_mask", "stream_levels", "stream_waves", "stream_chunks", "stream_slots", "stream_ppl", "rows_levels", "rows_cfg")
 
 
 def _run_both(oracle_tvl1, gray, **kw):
@@ -282,7 +282,11 @@ def test_bad_arguments_raise_value_error():
     with pytest.raises(ValueError):
         vflow.tvl1_flow(fr, out=torch.empty(1, 2, 64, 64, device="cuda"))  # out for 2 pairs must be [2,2,64,64]
     with pytest.raises(ValueError):
-        vflow.tvl1_flow(fr, tile_mask=1 << 9)  # 8 tile candidates + the streaming bit
+        vflow.tvl1_flow(fr, tile_mask=1 << 10)  # 8 tile candidates + the streaming bit + the row-pipeline bit
+    with pytest.raises(ValueError):
+        vflow.tvl1_flow(fr, rows_cfg=1000)
+    with pytest.raises(ValueError):
+        vflow.tvl1_flow(fr, stream_levels=-2)
     out = torch.empty(2, 2, 64, 64, device="cuda")
     got = vflow.tvl1_flow(fr, out=out)
     assert got.data_ptr() == out.data_ptr() and bool((got == 0).all())  # identical frames: zero flow, written in place

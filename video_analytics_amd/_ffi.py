@@ -45,6 +45,7 @@ class Tvl1Params(ctypes.Structure):
         ("stream_chunks", ctypes.c_int),
         ("stream_slots", ctypes.c_int),
         ("rows_levels", ctypes.c_int),
+        ("stream_ppl", ctypes.c_int),
         ("rows_cfg", ctypes.c_int),
     ]
 

@@ -334,6 +334,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef VA_REV
 #define VA_REV 1
 #endif
+#ifndef VA_STREAM_MIN_PX
+#define VA_STREAM_MIN_PX 40000.0  // smaller levels: too few strip x chunk jobs for the GPU, the register tiles win
+#endif
+#ifndef VA_STREAM_UNROLL2
+#define VA_STREAM_UNROLL2 1  // measured on the 224^2 level: 9.8 -> 9.3 ms per warp step of 320 pairs
+#endif
 #ifndef VA_CHUNK
 #define VA_CHUNK 1
 #endif
@@ -465,6 +471,9 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
     const float* __restrict__ sin = (inbuf ? a.stB : a.stA) + (size_t)pair * kNF_STATE * a.plane;
     float* __restrict__ sout = (inbuf ? a.outA : a.outB) + (size_t)pair * kNF_STATE * a.plane;
 
+    // columns a run may touch: up to the last 4-pixel run holding a valid pixel.  The row pitch can be larger (a level
+    // laid out for k_iter_rows): those columns are never read or written here (what they hold is arbitrary).
+    const int xlim = (w + 3) & ~3;
     f2 u1[C][RP], u2[C][RP], p11[C][RP], p12[C][RP], p21[C][RP], p22[C][RP];
     f2 wx[C][RP], wy[C][RP], rc[C][RP], ig[C][RP];
 #pragma clang loop unroll(full)
@@ -472,16 +481,16 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
         const int y = y0 + c;
         const bool rowok = y < h;
         const size_t ro_ = (size_t)y * pitch;
-        load_row<RP>(sin + ro_, x0, pitch, rowok, u1[c]);
-        load_row<RP>(sin + a.plane + ro_, x0, pitch, rowok, u2[c]);
-        load_row<RP>(sin + 2 * a.plane + ro_, x0, pitch, rowok, p11[c]);
-        load_row<RP>(sin + 3 * a.plane + ro_, x0, pitch, rowok, p12[c]);
-        load_row<RP>(sin + 4 * a.plane + ro_, x0, pitch, rowok, p21[c]);
-        load_row<RP>(sin + 5 * a.plane + ro_, x0, pitch, rowok, p22[c]);
-        load_row<RP>(ro + ro_, x0, pitch, rowok, wx[c]);
-        load_row<RP>(ro + a.plane + ro_, x0, pitch, rowok, wy[c]);
-        load_row<RP>(ro + 2 * a.plane + ro_, x0, pitch, rowok, rc[c]);
-        load_row<RP>(ro + 3 * a.plane + ro_, x0, pitch, rowok, ig[c]);
+        load_row<RP>(sin + ro_, x0, xlim, rowok, u1[c]);
+        load_row<RP>(sin + a.plane + ro_, x0, xlim, rowok, u2[c]);
+        load_row<RP>(sin + 2 * a.plane + ro_, x0, xlim, rowok, p11[c]);
+        load_row<RP>(sin + 3 * a.plane + ro_, x0, xlim, rowok, p12[c]);
+        load_row<RP>(sin + 4 * a.plane + ro_, x0, xlim, rowok, p21[c]);
+        load_row<RP>(sin + 5 * a.plane + ro_, x0, xlim, rowok, p22[c]);
+        load_row<RP>(ro + ro_, x0, xlim, rowok, wx[c]);
+        load_row<RP>(ro + a.plane + ro_, x0, xlim, rowok, wy[c]);
+        load_row<RP>(ro + 2 * a.plane + ro_, x0, xlim, rowok, rc[c]);
+        load_row<RP>(ro + 3 * a.plane + ro_, x0, xlim, rowok, ig[c]);
     }
 
     // Forward-difference border rule as 0/1 multipliers (x < w-1, y < h-1): exact (d*1 = d, d*0 = 0).
@@ -532,17 +541,20 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
 #pragma clang loop unroll(full)
         for (int cc = 0; cc < C; ++cc) {
             const int c = (C > 1 && cc < 2) ? 1 - cc : cc;
-            float l11 = dpp_from_left(p11[c][RP - 1].y), l21 = dpp_from_left(p21[c][RP - 1].y);
+            // backward difference across the lane boundary: a plain subtraction, so that the compiler folds the lane shift
+            // into it (one v_subrev_f32_dpp); in folded waves the first lane of a row group has no left neighbour in its
+            // row: it keeps p itself (= p - 0, what the 0/1 multiplier lfix used to produce)
+            float e11 = p11[c][0].x - dpp_from_left(p11[c][RP - 1].y), e21 = p21[c][0].x - dpp_from_left(p21[c][RP - 1].y);
             if constexpr (LX != 64) {
-                l11 *= lfix;
-                l21 *= lfix;
+                e11 = lfix != 0.0f ? e11 : p11[c][0].x;
+                e21 = lfix != 0.0f ? e21 : p21[c][0].x;
             }
 #pragma clang loop unroll(full)
             for (int j = 0; j < RP; ++j) {
                 // backward x differences in the interleaved layout (pack 0 = E = pixels x0, x0+2; pack 1 = O = x0+1,
                 // x0+3): O - E is one packed subtract; E needs the left lane's last pixel and O.x: two v_sub_f32
-                const f2 dx11 = j == 0 ? f2{sub_s(p11[c][0].x, l11), sub_s(p11[c][0].y, p11[c][1].x)} : p11[c][1] - p11[c][0];
-                const f2 dx21 = j == 0 ? f2{sub_s(p21[c][0].x, l21), sub_s(p21[c][0].y, p21[c][1].x)} : p21[c][1] - p21[c][0];
+                const f2 dx11 = j == 0 ? f2{e11, sub_s(p11[c][0].y, p11[c][1].x)} : p11[c][1] - p11[c][0];
+                const f2 dx21 = j == 0 ? f2{e21, sub_s(p21[c][0].y, p21[c][1].x)} : p21[c][1] - p21[c][0];
                 const f2 a12 = c > 0 ? p12[c > 0 ? c - 1 : 0][j] : A12[j];
                 const f2 a22 = c > 0 ? p22[c > 0 ? c - 1 : 0][j] : A22[j];
                 const f2 div1 = dx11 + (p12[c][j] - a12);
@@ -592,8 +604,8 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
 #pragma clang loop unroll(full)
             for (int j = 0; j < RP; ++j) {
                 // forward x differences: E's are O - E (packed); O's need E.y and the right lane's first pixel
-                const f2 d1x = j == 0 ? u1[c][1] - u1[c][0] : f2{sub_s(u1[c][0].y, u1[c][1].x), sub_s(r1, u1[c][1].y)};
-                const f2 d2x = j == 0 ? u2[c][1] - u2[c][0] : f2{sub_s(u2[c][0].y, u2[c][1].x), sub_s(r2, u2[c][1].y)};
+                const f2 d1x = j == 0 ? u1[c][1] - u1[c][0] : f2{sub_s(u1[c][0].y, u1[c][1].x), r1 - u1[c][1].y};
+                const f2 d2x = j == 0 ? u2[c][1] - u2[c][0] : f2{sub_s(u2[c][0].y, u2[c][1].x), r2 - u2[c][1].y};
                 const f2 b1 = c < C - 1 ? u1[c < C - 1 ? c + 1 : 0][j] : B1[j];
                 const f2 b2 = c < C - 1 ? u2[c < C - 1 ? c + 1 : 0][j] : B2[j];
                 const f2 u1x = d1x * mx[j], u1y = (b1 - u1[c][j]) * my[c];
@@ -641,12 +653,12 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
         const int y = y0 + c;
         if (runok && y >= vy0 && y < vy1 && y < h) {
             const size_t ro_ = (size_t)y * pitch;
-            store_row<RP>(sout + ro_, x0, pitch, u1[c]);
-            store_row<RP>(sout + a.plane + ro_, x0, pitch, u2[c]);
-            store_row<RP>(sout + 2 * a.plane + ro_, x0, pitch, p11[c]);
-            store_row<RP>(sout + 3 * a.plane + ro_, x0, pitch, p12[c]);
-            store_row<RP>(sout + 4 * a.plane + ro_, x0, pitch, p21[c]);
-            store_row<RP>(sout + 5 * a.plane + ro_, x0, pitch, p22[c]);
+            store_row<RP>(sout + ro_, x0, xlim, u1[c]);
+            store_row<RP>(sout + a.plane + ro_, x0, xlim, u2[c]);
+            store_row<RP>(sout + 2 * a.plane + ro_, x0, xlim, p11[c]);
+            store_row<RP>(sout + 3 * a.plane + ro_, x0, xlim, p12[c]);
+            store_row<RP>(sout + 4 * a.plane + ro_, x0, xlim, p21[c]);
+            store_row<RP>(sout + 5 * a.plane + ro_, x0, xlim, p22[c]);
         }
     }
     if constexpr (EPS) {
@@ -656,320 +668,10 @@ __global__ void __launch_bounds__(NW * 64) k_iter_tile(IterArgs a)
     }
 }
 
-// ---------------------------------------------------------------- streaming inner iterations ---
-//
-// k_iter_stream: the same S6 arithmetic organised as a time-skewed pipeline along y ("3.5-D blocking").  One WAVE owns a
-// strip of 128 columns (2 pixels per lane, plain row order) and a chunk of rows [a0, b0); it streams the rows of the
-// strip top to bottom ONCE per launch and carries every row through K iterations on the way: level t (t = 0 .. K-1)
-// turns the time-t values of its incoming row into time-(t+1) values one row behind, so level t works on row
-// (s - t) at step s.  A level keeps only ONE row of p (its row above) and one row of the new u (waiting for its row
-// below) in registers: 12 VGPRs per level, 120 for K = 10.  The per-warp constants of the K rows in flight sit in a
-// private LDS ring (each lane reads back only what it wrote: no barrier anywhere in the kernel).
-// Against k_iter_tile's overlapped tiles (halo K on four sides: 2.0x redundant work on the 224^2 level) a strip pays
-// the halo only in x where the level is wider than 128 columns and a triangular K(K+1) level-rows per chunk in y.
-struct StreamArgs {
-    const float* ro;
-    const float* sin;
-    float* sout;
-    size_t plane;
-    int w, h, pitch;
-    int nsx, nch, R, HX;  // strips per row, chunks per column, rows per chunk, x halo of interior strip edges
-    int K;                // iterations in this launch (<= KS)
-    int pair0, rev;
-    float l_t, taut, theta;
-};
-
-// KH levels per wave, NWV waves per workgroup.  NWV = 1: the wave is the whole pipeline (K <= KH iterations per pass).
-// NWV = 2: the second wave continues where the first stops -- it takes the rows that leave the first wave's level
-// KH-1 out of a double-buffered LDS row instead of HBM and carries them through levels KH .. 2KH-1, so that one pass
-// over the strip is worth K <= 2 KH iterations of HBM traffic; both waves share the ring of per-warp constants; one
-// workgroup barrier per step keeps them a step apart.
-template <int KH, int NWV, bool FAST>
-__global__ void __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_iter_stream(StreamArgs a)
-{
-    // ring rows: NWV = 1: level t >= 1 reads row s - t, row s is written at the end of step s.  NWV = 2: the first
-    // wave writes row s - 1 at the start of step s (after the barrier), the oldest row read in step s is
-    // s - (KH + 1) - (KH - 1) = s - 2 KH.
-    constexpr int NRING = NWV == 1 ? KH - 1 : NWV * KH;
-    __shared__ f2 ring[NRING][kNF_RO][64];
-    __shared__ f2 iface[NWV > 1 ? NWV - 1 : 1][2][kNF_STATE][64];
-
-    unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
-    {
-        const unsigned nb = gridDim.x * gridDim.y, q = nb / 8, r = nb % 8, xcd = lid % 8, kk = lid / 8;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
-        if (a.rev) lid = nb - 1 - lid;
-    }
-    const int pair = a.pair0 + (int)(lid / gridDim.x), job = (int)(lid % gridDim.x);
-    const int sx = job % a.nsx, ch = job / a.nsx;
-    const int w = a.w, h = a.h, pitch = a.pitch, K = a.K;
-    const int lane = threadIdx.x & 63;
-    const int wv = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int ox = sx * (128 - 2 * a.HX);
-    const int vx0 = ox + (sx > 0 ? a.HX : 0), vx1 = (sx == a.nsx - 1) ? pitch : ox + 128 - a.HX;
-    const int x0 = ox + 2 * lane;
-    const bool colok = x0 < pitch;
-    const bool stok = colok && x0 >= vx0 && x0 < vx1;
-    const int a0 = ch * a.R, b0 = d_min(h, a0 + a.R);
-    const int ys = d_max(0, a0 - K), ye = d_min(h, b0 + K);
-
-    // buffer addressing: resource (scalar) + per-lane byte offset (one VGPR) + scalar plane/row offset.  Lanes beyond the
-    // pitch read column 0 (finite values that no valid pixel can see: their differences are multiplied by mx = 0) and
-    // never store.
-    typedef unsigned u2v __attribute__((ext_vector_type(2)));
-    const int planeb = (int)(a.plane * sizeof(float)), pitchb = pitch * (int)sizeof(float);
-    const __amdgpu_buffer_rsrc_t rs_ro = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.ro + (size_t)pair * kNF_RO * a.plane), 0, kNF_RO * planeb, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.sin + (size_t)pair * kNF_STATE * a.plane), 0, kNF_STATE * planeb, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.sout + (size_t)pair * kNF_STATE * a.plane, 0,
-                                                                           kNF_STATE * planeb, 0x00020000);
-    const int loff = colok ? x0 * (int)sizeof(float) : 0;
-
-    const f2 mx = f2{x0 < w - 1 ? 1.0f : 0.0f, x0 + 1 < w - 1 ? 1.0f : 0.0f};
-    const float l_t = a.l_t;
-    const f2 taut = splat(a.taut), theta = splat(a.theta), one = splat(1.0f), zero = splat(0.0f);
-
-    for (int r = wv; r < NRING; r += NWV)
-#pragma clang loop unroll(full)
-        for (int f = 0; f < kNF_RO; ++f) ring[r][f][lane] = zero;
-    if constexpr (NWV > 1) {
-        if (wv == 0)
-#pragma clang loop unroll(full)
-            for (int f = 0; f < kNF_STATE; ++f) iface[0][0][f][lane] = iface[0][1][f][lane] = zero;
-        __syncthreads();
-    }
-
-    auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int f, int y) -> f2 {
-        return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, loff, f * planeb + y * pitchb, 0));
-    };
-    auto st = [&](f2 v, int f, int y) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), rs_out, loff, f * planeb + y * pitchb, 0); };
-
-    // level K-1 (in the last wave) emits row b0-1 when row b0 (or the dummy row h) comes in; every wave boundary adds a step
-    const int nsteps = b0 - ys + K + (NWV - 1);
-
-    auto run = [&](auto wave_tag) __attribute__((always_inline)) {
-        constexpr int W = decltype(wave_tag)::value;
-        constexpr bool FIRST = W == 0, LAST = W == NWV - 1;
-        constexpr int G0 = W * KH, LAG = W * (KH + 1);  // first level of this wave; steps it runs behind the first wave
-
-        f2 P11[KH], P12[KH], P21[KH], P22[KH], U1[KH], U2[KH];
-#pragma clang loop unroll(full)
-        for (int t = 0; t < KH; ++t) P11[t] = P12[t] = P21[t] = P22[t] = U1[t] = U2[t] = zero;
-        f2 nst[kNF_STATE], nro[kNF_RO], rprev[kNF_RO] = {zero, zero, zero, zero};
-#pragma clang loop unroll(full)
-        for (int f = 0; f < kNF_STATE; ++f) nst[f] = FIRST ? ld(rs_in, f, ys) : zero;
-#pragma clang loop unroll(full)
-        for (int f = 0; f < kNF_RO; ++f) nro[f] = FIRST ? ld(rs_ro, f, ys) : zero;
-
-        auto step = [&](const int s, auto steady_tag) __attribute__((always_inline)) {
-            constexpr bool STEADY = decltype(steady_tag)::value;
-            const int s0 = s % NRING;  // row s of the strip lives in ring slot s % NRING
-            f2 c_u1, c_u2, c_p11, c_p12, c_p21, c_p22;
-            f2 r0[kNF_RO] = {zero, zero, zero, zero};
-            if constexpr (FIRST) {
-                c_u1 = nst[0], c_u2 = nst[1], c_p11 = nst[2], c_p12 = nst[3], c_p21 = nst[4], c_p22 = nst[5];
-#pragma clang loop unroll(full)
-                for (int f = 0; f < kNF_RO; ++f) r0[f] = nro[f];
-                // next row (beyond the last row of the strip: row ye - 1 again -- finite values nobody uses, or, at the
-                // image bottom, the dummy row h whose only consumer multiplies its difference by my = 0)
-                const int rn = d_min(ys + s + 1, ye - 1);
-#pragma clang loop unroll(full)
-                for (int f = 0; f < kNF_STATE; ++f) nst[f] = ld(rs_in, f, rn);
-#pragma clang loop unroll(full)
-                for (int f = 0; f < kNF_RO; ++f) nro[f] = ld(rs_ro, f, rn);
-                if constexpr (NWV > 1) {  // the constants of row s - 1 go into the ring now that the barrier has passed
-                    const int sl = s0 == 0 ? NRING - 1 : s0 - 1;
-#pragma clang loop unroll(full)
-                    for (int f = 0; f < kNF_RO; ++f) ring[sl][f][lane] = rprev[f];
-                }
-                __builtin_amdgcn_sched_barrier(0);  // the loads stay at the top of the step: a whole step hides their latency
-            } else {
-                const int bsel = (s + 1) & 1;  // what the wave before wrote in step s - 1
-                c_u1 = iface[W - 1][bsel][0][lane];
-                c_u2 = iface[W - 1][bsel][1][lane];
-                c_p11 = iface[W - 1][bsel][2][lane];
-                c_p12 = iface[W - 1][bsel][3][lane];
-                c_p21 = iface[W - 1][bsel][4][lane];
-                c_p22 = iface[W - 1][bsel][5][lane];
-            }
-            // One level: phase A on the incoming row C (k_iter_tile's arithmetic, operation for operation), phase B on the
-            // row above it (whose lower neighbour is the row just computed); the level keeps the incoming p and the new u,
-            // and passes on (its old u, the new p) = the time-(t+1) values of the row above.
-            auto level = [&](int t, const f2 wx, const f2 wy, const f2 rc, const f2 ig, const f2 my) __attribute__((always_inline)) {
-                const float l11 = dpp_from_left(c_p11.y), l21 = dpp_from_left(c_p21.y);
-                const f2 dx11 = f2{sub_s(c_p11.x, l11), sub_s(c_p11.y, c_p11.x)};
-                const f2 dx21 = f2{sub_s(c_p21.x, l21), sub_s(c_p21.y, c_p21.x)};
-                const f2 div1 = dx11 + (c_p12 - P12[t]);
-                const f2 div2 = dx21 + (c_p22 - P22[t]);
-                const f2 rho = pk_fma(wy, c_u2, pk_fma(wx, c_u1, rc));
-                const f2 tt = -rho * ig;
-                const f2 fi = f2{__builtin_amdgcn_fmed3f(tt.x, -l_t, l_t), __builtin_amdgcn_fmed3f(tt.y, -l_t, l_t)};
-                const f2 v1 = pk_fma(fi, wx, c_u1);
-                const f2 v2 = pk_fma(fi, wy, c_u2);
-                const f2 n1 = pk_fma(theta, div1, v1);
-                const f2 n2 = pk_fma(theta, div2, v2);
-                const float r1 = dpp_from_right(U1[t].x), r2 = dpp_from_right(U2[t].x);
-                const f2 d1x = f2{sub_s(U1[t].y, U1[t].x), sub_s(r1, U1[t].y)};
-                const f2 d2x = f2{sub_s(U2[t].y, U2[t].x), sub_s(r2, U2[t].y)};
-                const f2 u1x = d1x * mx, u1y = (n1 - U1[t]) * my;
-                const f2 u2x = d2x * mx, u2y = (n2 - U2[t]) * my;
-                const f2 s1 = pk_fma(u1y, u1y, pk_fma(u1x, u1x, splat(kSqrtReg)));
-                const f2 s2 = pk_fma(u2y, u2y, pk_fma(u2x, u2x, splat(kSqrtReg)));
-                f2 q1, q2;
-                if constexpr (FAST) {
-                    const f2 g1 = f2{__builtin_amdgcn_sqrtf(s1.x), __builtin_amdgcn_sqrtf(s1.y)};
-                    const f2 g2 = f2{__builtin_amdgcn_sqrtf(s2.x), __builtin_amdgcn_sqrtf(s2.y)};
-                    const f2 d1 = pk_fma(taut, g1, one), d2 = pk_fma(taut, g2, one);
-                    q1 = f2{__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)};
-                    q2 = f2{__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)};
-                } else {
-                    const f2 g1 = sqrt_exact_pk(s1), g2 = sqrt_exact_pk(s2);
-                    const f2 d1 = pk_fma(taut, g1, one), d2 = pk_fma(taut, g2, one);
-                    const f2 rinv = rcp_exact_pk(d1 * d2);
-                    q1 = d2 * rinv;
-                    q2 = d1 * rinv;
-                }
-                const f2 o11 = pk_fma(taut, u1x, P11[t]) * q1;
-                const f2 o12 = pk_fma(taut, u1y, P12[t]) * q1;
-                const f2 o21 = pk_fma(taut, u2x, P21[t]) * q2;
-                const f2 o22 = pk_fma(taut, u2y, P22[t]) * q2;
-                const f2 ou1 = U1[t], ou2 = U2[t];
-                P11[t] = c_p11;
-                P12[t] = c_p12;
-                P21[t] = c_p21;
-                P22[t] = c_p22;
-                U1[t] = n1;
-                U2[t] = n2;
-                c_u1 = ou1;
-                c_u2 = ou2;
-                c_p11 = o11;
-                c_p12 = o12;
-                c_p21 = o21;
-                c_p22 = o22;
-            };
-            // ring slot of the constants of level t's incoming row, s - LAG - t
-            auto slot_of = [&](int t) {
-                const int c = (LAG + t) % NRING;
-                return s0 - c < 0 ? s0 - c + NRING : s0 - c;
-            };
-            const int rs = ys + s - LAG;  // the row coming into this wave's first level
-            bool emitted;
-            if constexpr (STEADY) {
-                // every level of the wave works and no row is the image's last: straight-line code; the constants of
-                // level t + 1 are fetched from the ring while level t computes
-                f2 q[kNF_RO] = {r0[0], r0[1], r0[2], r0[3]};
-                if constexpr (!FIRST) {
-                    const int slot = slot_of(0);
-#pragma clang loop unroll(full)
-                    for (int f = 0; f < kNF_RO; ++f) q[f] = ring[slot][f][lane];
-                }
-#pragma clang loop unroll(full)
-                for (int t = 0; t < KH; ++t) {
-                    f2 nq[kNF_RO] = {zero, zero, zero, zero};
-                    if (t + 1 < KH) {
-                        const int slot = slot_of(t + 1);
-#pragma clang loop unroll(full)
-                        for (int f = 0; f < kNF_RO; ++f) nq[f] = ring[slot][f][lane];
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    level(t, q[0], q[1], q[2], q[3], one);
-#pragma clang loop unroll(full)
-                    for (int f = 0; f < kNF_RO; ++f) q[f] = nq[f];
-                }
-                emitted = true;
-            } else {
-                emitted = false;
-#pragma clang loop unroll(full)
-                for (int t = 0; t < KH; ++t) {
-                    // global level g takes the rows [a0 - (K - g), b0 + (K - g)) of the image and, at the image bottom,
-                    // the dummy row h
-                    const int g = G0 + t, rin = rs - t;
-                    const int lo = d_max(0, a0 - (K - g)), hi = d_min(h, b0 + (K - g) - 1);
-                    const bool act = g < K && rin >= lo && rin <= hi;
-                    if (g == K - 1) emitted = act;
-                    if (act) {
-                        const f2 my = splat(rin - 1 < h - 1 ? 1.0f : 0.0f);
-                        if (FIRST && t == 0) {
-                            level(0, r0[0], r0[1], r0[2], r0[3], my);
-                        } else {
-                            const int slot = slot_of(t);
-                            level(t, ring[slot][0][lane], ring[slot][1][lane], ring[slot][2][lane], ring[slot][3][lane], my);
-                        }
-                    }
-                }
-            }
-            if constexpr (LAST) {
-                const int rout = ys + s - W - K;  // the row that left level K-1 in this step, K iterations on
-                if (emitted && stok && rout >= a0 && rout < b0) {
-                    st(c_u1, 0, rout);
-                    st(c_u2, 1, rout);
-                    st(c_p11, 2, rout);
-                    st(c_p12, 3, rout);
-                    st(c_p21, 4, rout);
-                    st(c_p22, 5, rout);
-                }
-            } else {
-                const int bsel = s & 1;
-                iface[W][bsel][0][lane] = c_u1;
-                iface[W][bsel][1][lane] = c_u2;
-                iface[W][bsel][2][lane] = c_p11;
-                iface[W][bsel][3][lane] = c_p12;
-                iface[W][bsel][4][lane] = c_p21;
-                iface[W][bsel][5][lane] = c_p22;
-            }
-            if constexpr (FIRST) {
-                if constexpr (NWV == 1) {
-#pragma clang loop unroll(full)
-                    for (int f = 0; f < kNF_RO; ++f) ring[s0][f][lane] = r0[f];
-                } else {
-#pragma clang loop unroll(full)
-                    for (int f = 0; f < kNF_RO; ++f) rprev[f] = r0[f];
-                }
-            }
-            // hand-over barrier: LDS traffic only (no wait for the global loads in flight or the stores just issued)
-            if constexpr (NWV > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        };
-        // steady state of this wave: steps [s_a, s_b) (all its KH levels inside their row windows, below the last row)
-        int s_a = d_max(KH - 1, a0 - K + G0 + 2 * KH - 2) - ys + LAG;
-        int s_b = d_min(nsteps, d_min(h - 1, b0 + K - G0 - 1) - ys + LAG + 1);
-        if (K < G0 + KH || s_a > s_b) s_a = s_b = 0;
-        int s = 0;
-        for (; s < s_a; ++s) step(s, std::false_type{});
-        for (; s < s_b; ++s) step(s, std::true_type{});
-        for (; s < nsteps; ++s) step(s, std::false_type{});
-    };
-    if constexpr (NWV == 1) {
-        run(std::integral_constant<int, 0>{});
-    } else {
-        if (wv == 0) run(std::integral_constant<int, 0>{});
-        else run(std::integral_constant<int, NWV - 1>{});
-    }
-}
-
-// ---------------------------------------------------------------- persistent row pipeline ------
-//
-// k_iter_rows: ALL `iters` inner iterations of one warp step in ONE launch, for levels that fit a single strip
-// (pitch <= 64 * PPL columns, PPL = 2, 3 or 4 pixels per lane: no x halo at all).  One workgroup owns one pair; its NWV
-// waves form the time-skewed row pipeline of k_iter_stream (wave W holds levels W*KH .. W*KH + KH - 1, rows are handed
-// from wave to wave through a double-buffered LDS row, one LDS-only barrier per step), but the pipeline never drains
-// between passes: the rows of pass n + 1 (read back from the buffer pass n wrote, K = NWV*KH iterations earlier in
-// time) follow the last row of pass n immediately, so the triangular fill/drain of a pass is paid once per launch
-// instead of once per K iterations, and there is no y halo and no launch boundary inside a warp step.
-//
-//  * Row identity travels with the row as one scalar: id = pass << 20 | ring slot << 14 | row (-1 = no row).  A level
-//    that holds a row emits it (one iteration on) when the next row arrives and keeps the arrival; a level that is not
-//    active for a row (its index >= the pass's depth) hands it on untouched.  Everything about identity is SALU work.
-//  * iters = K0 + (N - 1) K with the SHORT pass first: levels >= K0 are inactive for pass 0 and still hold their
-//    zero-initialised state when pass 1 reaches them, exactly as at the start of the kernel.
-//  * The image's last row is flushed by whatever row follows it (row 0 of the next pass, or dummy rows after the
-//    last pass): its forward y difference is multiplied by my = 0 whenever the arriving row has index 0.  A level in
-//    its initial state emits an exact zero row with no identity, which nobody stores.
-//  * Pass n + 1 reads row r at least h - K - NWV - 2 steps after pass n stored it; both happen on the same CU (one
-//    workgroup), whose vector L1 is write-through and coherent for its own waves: the storing wave drains its older
-//    stores (s_waitcnt vmcnt) before each step's barrier, nothing else is needed (no agent-scope fence).
-//  * The per-warp constants of the K + NWV rows in flight sit in an LDS ring written by the loading wave.
-// Same arithmetic as k_iter_tile / k_iter_stream, operation for operation: results are bit-identical.
+// ---------------------------------------------------------------- rows of N pixels per lane ---
+// A lane's N consecutive pixels of one field (N = 2, 3, 4) as N/2 packed pairs + a scalar tail: the arithmetic of the
+// row pipelines (k_iter_stream, k_iter_rows) is written once over these; pairs issue as v_pk_*_f32, the tail as plain
+// VALU -- element by element the same IEEE operations, so results do not depend on N.
 template <int N>
 struct Row {
     static constexpr int NP = N / 2, NT = N & 1;
@@ -1068,7 +770,7 @@ __device__ __forceinline__ Row<N> r_diff_back(const Row<N>& a)
 #pragma clang loop unroll(full)
     for (int i = 0; i < N; ++i) {
         const float cur = row_get(a, i);
-        row_set(d, i, sub_s(cur, prev));
+        row_set(d, i, i == 0 ? cur - prev : sub_s(cur, prev));  // plain across the lane boundary: folds into v_subrev_f32_dpp
         prev = cur;
     }
     return d;
@@ -1080,21 +782,10 @@ __device__ __forceinline__ Row<N> r_diff_fwd(const Row<N>& a)
     d.t = 0.0f;
     const float right = dpp_from_right(row_get(a, 0));
 #pragma clang loop unroll(full)
-    for (int i = 0; i < N; ++i) row_set(d, i, sub_s(i < N - 1 ? row_get(a, i + 1 < N ? i + 1 : 0) : right, row_get(a, i)));
+    for (int i = 0; i < N; ++i)
+        row_set(d, i, i < N - 1 ? sub_s(row_get(a, i + 1 < N ? i + 1 : 0), row_get(a, i)) : right - row_get(a, i));
     return d;
 }
-
-struct RowsArgs {
-    const float* ro;
-    float* st;            // the lower of the two state buffers (pair-major planes)
-    unsigned delta[2];    // byte offset of state buffer 0 / 1 from `st`
-    size_t plane;
-    int w, h, pitch;
-    int K, K0, N;         // iterations of a full pass (<= NWV*KH), of the first pass (1..K), number of passes
-    int cur;              // buffer index holding the input of pass 0
-    int pair0;
-    float l_t, taut, theta;
-};
 
 template <int PPL> struct RowIo;
 template <> struct RowIo<2> {
@@ -1130,6 +821,375 @@ __device__ __forceinline__ void row_store(const Row<N>& o, __amdgpu_buffer_rsrc_
     for (int i = 0; i < N; ++i) v[i] = __float_as_uint(row_get(o, i));
     RowIo<N>::st(v, r, vo, so);
 }
+
+
+// ---------------------------------------------------------------- streaming inner iterations ---
+//
+// k_iter_stream: the same S6 arithmetic organised as a time-skewed pipeline along y ("3.5-D blocking").  One WAVE owns a
+// strip of 128 columns (2 pixels per lane, plain row order) and a chunk of rows [a0, b0); it streams the rows of the
+// strip top to bottom ONCE per launch and carries every row through K iterations on the way: level t (t = 0 .. K-1)
+// turns the time-t values of its incoming row into time-(t+1) values one row behind, so level t works on row
+// (s - t) at step s.  A level keeps only ONE row of p (its row above) and one row of the new u (waiting for its row
+// below) in registers: 12 VGPRs per level, 120 for K = 10.  The per-warp constants of the K rows in flight sit in a
+// private LDS ring (each lane reads back only what it wrote: no barrier anywhere in the kernel).
+// Against k_iter_tile's overlapped tiles (halo K on four sides: 2.0x redundant work on the 224^2 level) a strip pays
+// the halo only in x where the level is wider than 128 columns and a triangular K(K+1) level-rows per chunk in y.
+struct StreamArgs {
+    const float* ro;
+    const float* sin;
+    float* sout;
+    size_t plane;
+    int w, h, pitch;
+    int nsx, nch, R, HX;  // strips per row, chunks per column, rows per chunk, x halo of interior strip edges
+    int K;                // iterations in this launch (<= KS)
+    int pair0, rev;
+    float l_t, taut, theta;
+};
+
+// KH levels per wave, NWV waves per workgroup.  NWV = 1: the wave is the whole pipeline (K <= KH iterations per pass).
+// NWV = 2: the second wave continues where the first stops -- it takes the rows that leave the first wave's level
+// KH-1 out of a double-buffered LDS row instead of HBM and carries them through levels KH .. 2KH-1, so that one pass
+// over the strip is worth K <= 2 KH iterations of HBM traffic; both waves share the ring of per-warp constants; one
+// workgroup barrier per step keeps them a step apart.
+// PPL pixels per lane: a strip is 64 * PPL columns wide (2: 128, the layout the kernel was tuned on; 3: 192, so that a
+// 129..192-column level is ONE well-filled strip without any x halo; 4: 256).
+template <int PPL, int KH, int NWV, bool FAST>
+__global__ void __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_iter_stream(StreamArgs a)
+{
+    typedef Row<PPL> R;
+    constexpr int NP = R::NP, NT = R::NT, SW = 64 * PPL;
+    // ring rows: NWV = 1: level t >= 1 reads row s - t, row s is written at the end of step s.  NWV = 2: the first
+    // wave writes row s - 1 at the start of step s (after the barrier), the oldest row read in step s is
+    // s - (KH + 1) - (KH - 1) = s - 2 KH.
+    constexpr int NRING = NWV == 1 ? KH - 1 : NWV * KH;
+    __shared__ f2 ringP[NRING][kNF_RO][NP][64];
+    __shared__ float ringT[NRING][kNF_RO][NT ? 64 : 1];
+    __shared__ f2 ifaceP[NWV > 1 ? NWV - 1 : 1][2][kNF_STATE][NP][64];
+    __shared__ float ifaceT[NWV > 1 ? NWV - 1 : 1][2][kNF_STATE][NT ? 64 : 1];
+
+    unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const unsigned nb = gridDim.x * gridDim.y, q = nb / 8, r = nb % 8, xcd = lid % 8, kk = lid / 8;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+        if (a.rev) lid = nb - 1 - lid;
+    }
+    const int pair = a.pair0 + (int)(lid / gridDim.x), job = (int)(lid % gridDim.x);
+    const int sx = job % a.nsx, ch = job / a.nsx;
+    const int w = a.w, h = a.h, pitch = a.pitch, K = a.K;
+    const int lane = threadIdx.x & 63;
+    const int wv = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ox = sx * (SW - 2 * a.HX);
+    const int vx0 = ox + (sx > 0 ? a.HX : 0), vx1 = (sx == a.nsx - 1) ? pitch : ox + SW - a.HX;
+    const int x0 = ox + PPL * lane;  // (the pitch, the halo and so every strip origin are multiples of PPL)
+    const bool colok = x0 < pitch;
+    const bool stok = colok && x0 >= vx0 && x0 < vx1;
+    const int a0 = ch * a.R, b0 = d_min(h, a0 + a.R);
+    const int ys = d_max(0, a0 - K), ye = d_min(h, b0 + K);
+
+    // buffer addressing: resource (scalar) + per-lane byte offset (one VGPR) + scalar plane/row offset.  Lanes beyond the
+    // pitch read column 0 (finite values that no valid pixel can see: their differences are multiplied by mx = 0) and
+    // never store.
+    const int planeb = (int)(a.plane * sizeof(float)), pitchb = pitch * (int)sizeof(float);
+    const __amdgpu_buffer_rsrc_t rs_ro = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.ro + (size_t)pair * kNF_RO * a.plane), 0, kNF_RO * planeb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.sin + (size_t)pair * kNF_STATE * a.plane), 0, kNF_STATE * planeb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.sout + (size_t)pair * kNF_STATE * a.plane, 0,
+                                                                           kNF_STATE * planeb, 0x00020000);
+    const int loff = colok ? x0 * (int)sizeof(float) : 0;
+
+    R mx;
+    mx.t = 0.0f;
+#pragma clang loop unroll(full)
+    for (int i = 0; i < PPL; ++i) row_set(mx, i, x0 + i < w - 1 ? 1.0f : 0.0f);
+    const float l_t = a.l_t, taut = a.taut, theta = a.theta;
+    const R zero = row_splat<PPL>(0.0f), one = row_splat<PPL>(1.0f);
+
+    auto ring_put = [&](int slot, int f, const R& v) __attribute__((always_inline)) {
+#pragma clang loop unroll(full)
+        for (int j = 0; j < NP; ++j) ringP[slot][f][j][lane] = v.p[j];
+        if constexpr (NT) ringT[slot][f][lane] = v.t;
+    };
+    auto ring_get = [&](int slot, int f) __attribute__((always_inline)) -> R {
+        R v;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < NP; ++j) v.p[j] = ringP[slot][f][j][lane];
+        v.t = 0.0f;
+        if constexpr (NT) v.t = ringT[slot][f][lane];
+        return v;
+    };
+    auto if_put = [&](int wb, int b, int f, const R& v) __attribute__((always_inline)) {
+#pragma clang loop unroll(full)
+        for (int j = 0; j < NP; ++j) ifaceP[wb][b][f][j][lane] = v.p[j];
+        if constexpr (NT) ifaceT[wb][b][f][lane] = v.t;
+    };
+    auto if_get = [&](int wb, int b, int f) __attribute__((always_inline)) -> R {
+        R v;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < NP; ++j) v.p[j] = ifaceP[wb][b][f][j][lane];
+        v.t = 0.0f;
+        if constexpr (NT) v.t = ifaceT[wb][b][f][lane];
+        return v;
+    };
+
+    for (int r = wv; r < NRING; r += NWV)
+#pragma clang loop unroll(full)
+        for (int f = 0; f < kNF_RO; ++f) ring_put(r, f, zero);
+    if constexpr (NWV > 1) {
+        if (wv == 0)
+#pragma clang loop unroll(full)
+            for (int f = 0; f < kNF_STATE; ++f) {
+                if_put(0, 0, f, zero);
+                if_put(0, 1, f, zero);
+            }
+        __syncthreads();
+    }
+
+    auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int f, int y) -> R { return row_load<PPL>(r, loff, f * planeb + y * pitchb); };
+    auto st = [&](const R& v, int f, int y) { row_store<PPL>(v, rs_out, loff, f * planeb + y * pitchb); };
+
+    // level K-1 (in the last wave) emits row b0-1 when row b0 (or the dummy row h) comes in; every wave boundary adds a step
+    const int nsteps = b0 - ys + K + (NWV - 1);
+
+    auto run = [&](auto wave_tag) __attribute__((always_inline)) {
+        constexpr int W = decltype(wave_tag)::value;
+        constexpr bool FIRST = W == 0, LAST = W == NWV - 1;
+        constexpr int G0 = W * KH, LAG = W * (KH + 1);  // first level of this wave; steps it runs behind the first wave
+
+        R P11[KH], P12[KH], P21[KH], P22[KH], U1[KH], U2[KH];
+#pragma clang loop unroll(full)
+        for (int t = 0; t < KH; ++t) P11[t] = P12[t] = P21[t] = P22[t] = U1[t] = U2[t] = zero;
+        R nst[kNF_STATE], nro[kNF_RO], rprev[kNF_RO] = {zero, zero, zero, zero};
+#pragma clang loop unroll(full)
+        for (int f = 0; f < kNF_STATE; ++f) nst[f] = FIRST ? ld(rs_in, f, ys) : zero;
+#pragma clang loop unroll(full)
+        for (int f = 0; f < kNF_RO; ++f) nro[f] = FIRST ? ld(rs_ro, f, ys) : zero;
+
+        auto step = [&](const int s, auto steady_tag) __attribute__((always_inline)) {
+            constexpr bool STEADY = decltype(steady_tag)::value;
+            const int s0 = s % NRING;  // row s of the strip lives in ring slot s % NRING
+            R c_u1, c_u2, c_p11, c_p12, c_p21, c_p22;
+            R r0[kNF_RO] = {zero, zero, zero, zero};
+            if constexpr (FIRST) {
+                c_u1 = nst[0], c_u2 = nst[1], c_p11 = nst[2], c_p12 = nst[3], c_p21 = nst[4], c_p22 = nst[5];
+#pragma clang loop unroll(full)
+                for (int f = 0; f < kNF_RO; ++f) r0[f] = nro[f];
+                // next row (beyond the last row of the strip: row ye - 1 again -- finite values nobody uses, or, at the
+                // image bottom, the dummy row h whose only consumer multiplies its difference by my = 0)
+                const int rn = d_min(ys + s + 1, ye - 1);
+#pragma clang loop unroll(full)
+                for (int f = 0; f < kNF_STATE; ++f) nst[f] = ld(rs_in, f, rn);
+#pragma clang loop unroll(full)
+                for (int f = 0; f < kNF_RO; ++f) nro[f] = ld(rs_ro, f, rn);
+                if constexpr (NWV > 1) {  // the constants of row s - 1 go into the ring now that the barrier has passed
+                    const int sl = s0 == 0 ? NRING - 1 : s0 - 1;
+#pragma clang loop unroll(full)
+                    for (int f = 0; f < kNF_RO; ++f) ring_put(sl, f, rprev[f]);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // the loads stay at the top of the step: a whole step hides their latency
+            } else {
+                const int bsel = (s + 1) & 1;  // what the wave before wrote in step s - 1
+                c_u1 = if_get(W - 1, bsel, 0);
+                c_u2 = if_get(W - 1, bsel, 1);
+                c_p11 = if_get(W - 1, bsel, 2);
+                c_p12 = if_get(W - 1, bsel, 3);
+                c_p21 = if_get(W - 1, bsel, 4);
+                c_p22 = if_get(W - 1, bsel, 5);
+            }
+            // One level: phase A on the incoming row C (k_iter_tile's arithmetic, operation for operation), phase B on the
+            // row above it (whose lower neighbour is the row just computed); the level keeps the incoming p and the new u,
+            // and passes on (its old u, the new p) = the time-(t+1) values of the row above.
+            // MY1: the row the level holds is not the image's last one (my = 1): its y differences need no multiplier
+            // (x * 1 = x exactly; the straight-line steady-state steps use this form)
+            auto level = [&](int t, const R& wx, const R& wy, const R& rc, const R& ig, const float my, auto my1_tag) __attribute__((always_inline)) {
+                constexpr bool MY1 = decltype(my1_tag)::value;
+                // (the difference across the lane boundary is a plain subtraction inside r_diff_*: the compiler folds the
+                // lane shift into it -- one v_subrev_f32_dpp instead of v_mov_b32_dpp + v_sub_f32)
+                const R dx11 = r_diff_back(c_p11), dx21 = r_diff_back(c_p21);
+                const R div1 = r_add(dx11, r_sub(c_p12, P12[t]));
+                const R div2 = r_add(dx21, r_sub(c_p22, P22[t]));
+                const R rho = r_fma(wy, c_u2, r_fma(wx, c_u1, rc));
+                const R tt = r_negmul(rho, ig);
+                const R fi = r_med3(tt, -l_t, l_t);
+                const R v1 = r_fma(fi, wx, c_u1);
+                const R v2 = r_fma(fi, wy, c_u2);
+                const R n1 = r_fma_s(theta, div1, v1);
+                const R n2 = r_fma_s(theta, div2, v2);
+                const R d1x = r_diff_fwd(U1[t]), d2x = r_diff_fwd(U2[t]);
+                const R u1x = r_mul(d1x, mx), u1y = MY1 ? r_sub(n1, U1[t]) : r_mul_s(r_sub(n1, U1[t]), my);
+                const R u2x = r_mul(d2x, mx), u2y = MY1 ? r_sub(n2, U2[t]) : r_mul_s(r_sub(n2, U2[t]), my);
+                const R s1 = r_fma(u1y, u1y, r_fma_c(u1x, u1x, kSqrtReg));
+                const R s2 = r_fma(u2y, u2y, r_fma_c(u2x, u2x, kSqrtReg));
+                const R d1 = r_fma_s(taut, r_sqrt<PPL, FAST>(s1), one);
+                const R d2 = r_fma_s(taut, r_sqrt<PPL, FAST>(s2), one);
+                R q1, q2;
+                if constexpr (FAST) {
+                    q1 = r_rcp<PPL, true>(d1);
+                    q2 = r_rcp<PPL, true>(d2);
+                } else {
+                    const R rinv = r_rcp<PPL, false>(r_mul(d1, d2));
+                    q1 = r_mul(d2, rinv);
+                    q2 = r_mul(d1, rinv);
+                }
+                const R o11 = r_mul(r_fma_s(taut, u1x, P11[t]), q1);
+                const R o12 = r_mul(r_fma_s(taut, u1y, P12[t]), q1);
+                const R o21 = r_mul(r_fma_s(taut, u2x, P21[t]), q2);
+                const R o22 = r_mul(r_fma_s(taut, u2y, P22[t]), q2);
+                const R ou1 = U1[t], ou2 = U2[t];
+                P11[t] = c_p11;
+                P12[t] = c_p12;
+                P21[t] = c_p21;
+                P22[t] = c_p22;
+                U1[t] = n1;
+                U2[t] = n2;
+                c_u1 = ou1;
+                c_u2 = ou2;
+                c_p11 = o11;
+                c_p12 = o12;
+                c_p21 = o21;
+                c_p22 = o22;
+            };
+            // ring slot of the constants of level t's incoming row, s - LAG - t
+            auto slot_of = [&](int t) {
+                const int c = (LAG + t) % NRING;
+                return s0 - c < 0 ? s0 - c + NRING : s0 - c;
+            };
+            const int rs = ys + s - LAG;  // the row coming into this wave's first level
+            bool emitted;
+            if constexpr (STEADY) {
+                // every level of the wave works and no row is the image's last: straight-line code; the constants of
+                // level t + 1 are fetched from the ring while level t computes
+                R q[kNF_RO] = {r0[0], r0[1], r0[2], r0[3]};
+                if constexpr (!FIRST) {
+                    const int slot = slot_of(0);
+#pragma clang loop unroll(full)
+                    for (int f = 0; f < kNF_RO; ++f) q[f] = ring_get(slot, f);
+                }
+#pragma clang loop unroll(full)
+                for (int t = 0; t < KH; ++t) {
+                    R nq[kNF_RO] = {zero, zero, zero, zero};
+                    if (t + 1 < KH) {
+                        const int slot = slot_of(t + 1);
+#pragma clang loop unroll(full)
+                        for (int f = 0; f < kNF_RO; ++f) nq[f] = ring_get(slot, f);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    level(t, q[0], q[1], q[2], q[3], 1.0f, std::true_type{});
+#pragma clang loop unroll(full)
+                    for (int f = 0; f < kNF_RO; ++f) q[f] = nq[f];
+                }
+                emitted = true;
+            } else {
+                emitted = false;
+#pragma clang loop unroll(full)
+                for (int t = 0; t < KH; ++t) {
+                    // global level g takes the rows [a0 - (K - g), b0 + (K - g)) of the image and, at the image bottom,
+                    // the dummy row h
+                    const int g = G0 + t, rin = rs - t;
+                    const int lo = d_max(0, a0 - (K - g)), hi = d_min(h, b0 + (K - g) - 1);
+                    const bool act = g < K && rin >= lo && rin <= hi;
+                    if (g == K - 1) emitted = act;
+                    if (act) {
+                        const float my = rin - 1 < h - 1 ? 1.0f : 0.0f;
+                        if (FIRST && t == 0) {
+                            level(0, r0[0], r0[1], r0[2], r0[3], my, std::false_type{});
+                        } else {
+                            const int slot = slot_of(t);
+                            level(t, ring_get(slot, 0), ring_get(slot, 1), ring_get(slot, 2), ring_get(slot, 3), my, std::false_type{});
+                        }
+                    }
+                }
+            }
+            if constexpr (LAST) {
+                const int rout = ys + s - W - K;  // the row that left level K-1 in this step, K iterations on
+                if (emitted && stok && rout >= a0 && rout < b0) {
+                    st(c_u1, 0, rout);
+                    st(c_u2, 1, rout);
+                    st(c_p11, 2, rout);
+                    st(c_p12, 3, rout);
+                    st(c_p21, 4, rout);
+                    st(c_p22, 5, rout);
+                }
+            } else {
+                const int bsel = s & 1;
+                if_put(W, bsel, 0, c_u1);
+                if_put(W, bsel, 1, c_u2);
+                if_put(W, bsel, 2, c_p11);
+                if_put(W, bsel, 3, c_p12);
+                if_put(W, bsel, 4, c_p21);
+                if_put(W, bsel, 5, c_p22);
+            }
+            if constexpr (FIRST) {
+                if constexpr (NWV == 1) {
+#pragma clang loop unroll(full)
+                    for (int f = 0; f < kNF_RO; ++f) ring_put(s0, f, r0[f]);
+                } else {
+#pragma clang loop unroll(full)
+                    for (int f = 0; f < kNF_RO; ++f) rprev[f] = r0[f];
+                }
+            }
+            // hand-over barrier: LDS traffic only (no wait for the global loads in flight or the stores just issued)
+            if constexpr (NWV > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        // steady state of this wave: steps [s_a, s_b) (all its KH levels inside their row windows, below the last row)
+        int s_a = d_max(KH - 1, a0 - K + G0 + 2 * KH - 2) - ys + LAG;
+        int s_b = d_min(nsteps, d_min(h - 1, b0 + K - G0 - 1) - ys + LAG + 1);
+        if (K < G0 + KH || s_a > s_b) s_a = s_b = 0;
+        int s = 0;
+        for (; s < s_a; ++s) step(s, std::false_type{});
+#if VA_STREAM_UNROLL2
+        // two steady steps per loop trip: the rows a level hands on and keeps (c_* -> P[t], n -> U[t]) change registers
+        // by renaming between the two copies instead of by v_mov (5 per level and step otherwise)
+        for (; s + 1 < s_b; s += 2) {
+            step(s, std::true_type{});
+            step(s + 1, std::true_type{});
+        }
+#endif
+        for (; s < s_b; ++s) step(s, std::true_type{});
+        for (; s < nsteps; ++s) step(s, std::false_type{});
+    };
+    if constexpr (NWV == 1) {
+        run(std::integral_constant<int, 0>{});
+    } else {
+        if (wv == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, NWV - 1>{});
+    }
+}
+
+// ---------------------------------------------------------------- persistent row pipeline ------
+//
+// k_iter_rows: ALL `iters` inner iterations of one warp step in ONE launch, for levels that fit a single strip
+// (pitch <= 64 * PPL columns, PPL = 2, 3 or 4 pixels per lane: no x halo at all).  One workgroup owns one pair; its NWV
+// waves form the time-skewed row pipeline of k_iter_stream (wave W holds levels W*KH .. W*KH + KH - 1, rows are handed
+// from wave to wave through a double-buffered LDS row, one LDS-only barrier per step), but the pipeline never drains
+// between passes: the rows of pass n + 1 (read back from the buffer pass n wrote, K = NWV*KH iterations earlier in
+// time) follow the last row of pass n immediately, so the triangular fill/drain of a pass is paid once per launch
+// instead of once per K iterations, and there is no y halo and no launch boundary inside a warp step.
+//
+//  * Row identity travels with the row as one scalar: id = pass << 20 | ring slot << 14 | row (-1 = no row).  A level
+//    that holds a row emits it (one iteration on) when the next row arrives and keeps the arrival; a level that is not
+//    active for a row (its index >= the pass's depth) hands it on untouched.  Everything about identity is SALU work.
+//  * iters = K0 + (N - 1) K with the SHORT pass first: levels >= K0 are inactive for pass 0 and still hold their
+//    zero-initialised state when pass 1 reaches them, exactly as at the start of the kernel.
+//  * The image's last row is flushed by whatever row follows it (row 0 of the next pass, or dummy rows after the
+//    last pass): its forward y difference is multiplied by my = 0 whenever the arriving row has index 0.  A level in
+//    its initial state emits an exact zero row with no identity, which nobody stores.
+//  * Pass n + 1 reads row r at least h - K - NWV - 2 steps after pass n stored it; both happen on the same CU (one
+//    workgroup), whose vector L1 is write-through and coherent for its own waves: the storing wave drains its older
+//    stores (s_waitcnt vmcnt) before each step's barrier, nothing else is needed (no agent-scope fence).
+//  * The per-warp constants of the K + NWV rows in flight sit in an LDS ring written by the loading wave.
+// Same arithmetic as k_iter_tile / k_iter_stream, operation for operation: results are bit-identical.
+struct RowsArgs {
+    const float* ro;
+    float* st;            // the lower of the two state buffers (pair-major planes)
+    unsigned delta[2];    // byte offset of state buffer 0 / 1 from `st`
+    size_t plane;
+    int w, h, pitch;
+    int K, K0, N;         // iterations of a full pass (<= NWV*KH), of the first pass (1..K), number of passes
+    int cur;              // buffer index holding the input of pass 0
+    int pair0;
+    float l_t, taut, theta;
+};
 
 constexpr int kRowIdRowBits = 14, kRowIdSlotBits = 6;  // id = pass << 20 | slot << 14 | row
 
@@ -1475,16 +1535,33 @@ constexpr int kStreamK1 = 10;       // one-wave pipeline: iterations per pass
 constexpr int kStreamKH2 = 8;       // two-wave pipeline: levels per wave (16 iterations per pass)
 constexpr int kStreamBit = 1 << 8;  // va_tvl1_params.tile_mask bit: iterate with k_iter_stream
 struct StreamPick {
-    int nsx, nch, R, HX, two;
+    int nsx, nch, R, HX, two, ppl;
 };
+// Pixels per lane of k_iter_stream on a level of width w: 3 (192-column strips) where that makes the level ONE strip
+// with no x halo (129 .. 192 columns: 179^2 fills 93 % of the lanes instead of 70 % of two 128-column strips), else 2.
+// va_tvl1_params.stream_ppl forces 2, 3 or 4.
+int stream_ppl(const va_tvl1_params* p, int w)
+{
+    if (p->stream_ppl >= 2 && p->stream_ppl <= 4) return p->stream_ppl;
+    return (w > 128 && w <= 192) ? 3 : 2;
+}
+template <int KH, int NWV, bool FAST>
+void launch_stream(int ppl, dim3 grid, int threads, hipStream_t st, const StreamArgs& sa)
+{
+    if (ppl == 3) k_iter_stream<3, KH, NWV, FAST><<<grid, threads, 0, st>>>(sa);
+    else if (ppl == 4) k_iter_stream<4, KH, NWV, FAST><<<grid, threads, 0, st>>>(sa);
+    else k_iter_stream<2, KH, NWV, FAST><<<grid, threads, 0, st>>>(sa);
+}
 // Strips of a level.  Two-wave pipeline (16 iterations per pass) where the deeper x halo costs nothing, i.e. where the
 // level has no interior strip (w <= 224); wider levels use the one-wave pipeline (10 per pass, halo 10: measured on
 // the 1280x720 pyramid).  va_tvl1_params.stream_waves = 1 (experiment switch): one-wave everywhere.
 void stream_strips(const va_tvl1_params* p, int w, StreamPick& sp)
 {
-    sp.two = p->stream_waves != 1 && tiles_1d(w, 128, 2 * kStreamKH2) <= 2;
-    sp.HX = sp.two ? 2 * kStreamKH2 : kStreamK1;  // even: strip origins stay 8-byte aligned
-    sp.nsx = tiles_1d(w, 128, sp.HX);
+    sp.ppl = stream_ppl(p, w);
+    const int SW = 64 * sp.ppl, hq = sp.ppl == 3 ? 3 : 2;  // strip origins stay multiples of the pixels per lane
+    sp.two = p->stream_waves != 1 && tiles_1d(w, SW, va_cdiv(2 * kStreamKH2, hq) * hq) <= 2;
+    sp.HX = va_cdiv(sp.two ? 2 * kStreamKH2 : kStreamK1, hq) * hq;
+    sp.nsx = tiles_1d(w, SW, sp.HX);
 }
 StreamPick pick_stream(const va_tvl1_params* p, int w, int h, int npairs)
 {
@@ -1514,7 +1591,7 @@ bool level_streams(const va_tvl1_params* p, bool eps, int s, int w, int h, size_
     if (p->stream_levels >= 0) return ((p->stream_levels >> s) & 1) != 0;
     StreamPick sp{};
     stream_strips(p, w, sp);
-    return (double)w >= 0.75 * 128.0 * sp.nsx && (double)w * h >= 40000.0;
+    return (double)w >= 0.75 * 64.0 * sp.ppl * sp.nsx && (double)w * h >= VA_STREAM_MIN_PX;
 }
 
 // ---- k_iter_rows: which levels, which pipeline shape
@@ -1550,7 +1627,7 @@ bool pick_rows(const va_tvl1_params* p, int h, int pitch, RowsPick& rp)
     rp.K = p->iters < Kfull ? p->iters : Kfull;
     rp.N = va_cdiv(p->iters, rp.K);
     rp.K0 = p->iters - (rp.N - 1) * rp.K;
-    if (rp.N >= 2047) return false;                 // the pass index must fit the row identity
+    if (rp.N >= 2047 || pitch % rp.ppl != 0) return false;  // the pass index must fit the row identity; whole lanes per row
     // pass n + 1 reads a row back at least two steps after pass n stored it
     return h >= Kfull + nwv + 4 && h < (1 << kRowIdRowBits);
 }
@@ -1608,12 +1685,33 @@ int chunk_pairs(int lw, int lh, const TilePick& tp, int NP)
     return va_cdiv(NP, n);
 }
 
-// Row pitch in floats: a multiple of 12, so that rows start 16-byte aligned (k_iter_tile's 4-pixel runs) and a lane's 2,
-// 3 or 4 consecutive pixels (k_iter_stream, k_iter_rows) never straddle the end of a row.
-int level_pitch(int w) { return (w + 11) / 12 * 12; }
+// Row pitch in floats: the width rounded up to 4 (rows start 16-byte aligned: k_iter_tile's 4-pixel runs); a level that
+// k_iter_rows iterates gets a multiple of 12 instead, so that a lane's 2, 3 or 4 consecutive pixels never straddle the
+// end of a row.
+int level_pitch(int w, bool rows) { return rows ? (w + 11) / 12 * 12 : (w + 3) / 4 * 4; }
+// kernel and layout of level s: decided once, on the k_iter_rows layout (if the level does not qualify it keeps the
+// plain one)
+int plan_level(const va_tvl1_params* p, int s, int w, int h, int* pitch, size_t* plane, RowsPick* rp)
+{
+    const bool eps = p->epsilon > 0.0f;
+    const int p12 = level_pitch(w, true);
+    int lk = level_kernel(p, eps, s, w, h, p12, va_align_up((size_t)p12 * h, 64), rp);
+    *pitch = level_pitch(w, lk == LK_ROWS);
+    *plane = va_align_up((size_t)*pitch * h, 64);
+    if (lk != LK_ROWS) {
+        lk = level_kernel(p, eps, s, w, h, *pitch, *plane, nullptr) == LK_STREAM ? LK_STREAM : LK_TILE;
+        if (lk == LK_STREAM && stream_ppl(p, w) == 3) {  // three pixels per lane: whole lanes per row need a pitch % 3 == 0
+            *pitch = p12;
+            *plane = va_align_up((size_t)p12 * h, 64);
+        }
+    }
+    return lk;
+}
 
 struct Plan {
     int ns, ws[kMaxScales], hs[kMaxScales], pitch[kMaxScales];
+    int lk[kMaxScales];        // LK_TILE / LK_STREAM / LK_ROWS per level
+    RowsPick rows[kMaxScales];
     size_t plane[kMaxScales];
     int NF, NP, F;
     size_t off_pyr[kMaxScales], off_tmp, off_state[2], off_ro, off_err, off_sel, total;
@@ -1648,6 +1746,7 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
     VA_CHECK_ARG(p->tile_mask >= 0 && p->tile_mask < (1 << (kNumCfgs + 2)), "va_tvl1: tile_mask must be in [0, %d]", (1 << (kNumCfgs + 2)) - 1);
     VA_CHECK_ARG(p->rows_levels >= -1 && p->rows_levels < (1 << kMaxScales) && p->rows_cfg >= 0 && p->rows_cfg < 256,
                  "va_tvl1: rows_levels must be -1 or a level bit set, rows_cfg in [0,255]");
+    VA_CHECK_ARG(p->stream_ppl == 0 || (p->stream_ppl >= 2 && p->stream_ppl <= 4), "va_tvl1: stream_ppl must be 0 (automatic), 2, 3 or 4");
     VA_CHECK_ARG(p->stream_levels >= -1 && p->stream_levels < (1 << kMaxScales) && (p->stream_waves == 0 || p->stream_waves == 1) &&
                      p->stream_chunks >= 0 && p->stream_slots >= 0,
                  "va_tvl1: stream_levels must be -1 or a level bit set, stream_waves 0 or 1, stream_chunks and stream_slots >= 0");
@@ -1680,8 +1779,7 @@ void make_plan(Plan& P, int w, int h, int n_seq, int fps, const va_tvl1_params* 
     P.NP = n_seq * (fps - 1);
     size_t off = 0;
     for (int s = 0; s < P.ns; ++s) {
-        P.pitch[s] = level_pitch(P.ws[s]);
-        P.plane[s] = va_align_up((size_t)P.pitch[s] * P.hs[s], 64);
+        P.lk[s] = plan_level(p, s, P.ws[s], P.hs[s], &P.pitch[s], &P.plane[s], &P.rows[s]);
         P.off_pyr[s] = off;
         off += va_align_up((size_t)P.NF * 3 * P.plane[s] * sizeof(float), 256);
     }
@@ -1691,6 +1789,11 @@ void make_plan(Plan& P, int w, int h, int n_seq, int fps, const va_tvl1_params* 
         P.off_state[b] = off;
         off += va_align_up((size_t)P.NP * kNF_STATE * P.plane[0] * sizeof(float), 256);
     }
+    // k_iter_rows reaches both state buffers through one 32-bit buffer resource; a batch too large for that streams instead
+    // (same plain row order, any even pitch)
+    for (int s = 0; s < P.ns; ++s)
+        if (P.lk[s] == LK_ROWS && (P.off_state[1] - P.off_state[0]) + (size_t)kNF_STATE * P.plane[s] * sizeof(float) >= 2147483648ull)
+            P.lk[s] = LK_STREAM;
     P.off_ro = off;
     off += va_align_up((size_t)P.NP * kNF_RO * P.plane[0] * sizeof(float), 256);
     P.off_err = off;
@@ -1735,6 +1838,7 @@ extern "C" void va_tvl1_default_params(va_tvl1_params* p)
     p->stream_slots = 0;
     p->rows_levels = -1;
     p->rows_cfg = 0;
+    p->stream_ppl = 0;
 }
 
 extern "C" int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* hs)
@@ -1756,9 +1860,10 @@ extern "C" int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out
         const unsigned tmask = (unsigned)p->tile_mask & (unsigned)(kStreamBit - 1);
         const TilePick tp = K0 > 0 ? pick_tiles(ws[s], hs[s], K0, tmask) : pick_tiles_auto(ws[s], hs[s], p->iters, tmask);
         const TileCfg& c = kCfgs[tp.cfg];
-        const int lp = level_pitch(ws[s]);
+        int lp;
+        size_t lplane;
         RowsPick rp{};
-        const int lk = level_kernel(p, p->epsilon > 0.0f, s, ws[s], hs[s], lp, va_align_up((size_t)lp * hs[s], 64), &rp);
+        const int lk = plan_level(p, s, ws[s], hs[s], &lp, &lplane, &rp);
         if (lk == LK_ROWS) {
             const int plan[6] = {64 * rp.ppl, 0, rp.nwv, rp.K, 1, 0};
             memcpy(out + 6 * s, plan, sizeof(plan));
@@ -1767,7 +1872,7 @@ extern "C" int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out
         if (lk == LK_STREAM) {
             StreamPick sp{};
             stream_strips(p, ws[s], sp);
-            const int plan[6] = {128, 0, sp.two ? 2 : 1, sp.HX, sp.nsx, 0};
+            const int plan[6] = {64 * sp.ppl, 0, sp.two ? 2 : 1, sp.two ? 2 * kStreamKH2 : kStreamK1, sp.nsx, 0};
             memcpy(out + 6 * s, plan, sizeof(plan));
             continue;
         }
@@ -1857,12 +1962,15 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
         const size_t plane = P.plane[s];
         const unsigned tmask = (unsigned)p->tile_mask & (unsigned)(kStreamBit - 1);
         const TilePick tp = K0 > 0 ? pick_tiles(lw, lh, K0, tmask) : pick_tiles_auto(lw, lh, p->iters, tmask);
-        RowsPick rp{};
-        int lk = level_kernel(p, eps, s, lw, lh, lp, plane, &rp);
+        const RowsPick rp = P.rows[s];
+        const int lk = P.lk[s];
         // k_iter_rows addresses both state buffers through one 32-bit buffer resource
         const size_t st_lo = state[0] < state[1] ? 0 : 1;
         const size_t st_span = (size_t)((char*)state[st_lo ^ 1] - (char*)state[st_lo]) + (size_t)kNF_STATE * plane * sizeof(float);
-        if (lk == LK_ROWS && st_span >= 2147483648ull) lk = level_streams(p, eps, s, lw, lh, plane) ? LK_STREAM : LK_TILE;
+        if (lk == LK_ROWS && st_span >= 2147483648ull) {
+            va_set_error("va_tvl1_flow: internal error: state buffers too far apart for k_iter_rows");
+            return VA_ERR_INVALID;
+        }
         const bool strm = lk == LK_STREAM, rows = lk == LK_ROWS;
         const int perm = (strm || rows) ? 0 : 1;
         if (lp != lw) {
@@ -1963,11 +2071,11 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                     sa.sout = state[cur ^ 1];
                     sa.rev = VA_REV ? (launches & 1) : 0;
                     if (w2) {
-                        if (p->fast_math) k_iter_stream<kStreamKH2, 2, true><<<grid, 128, 0, st>>>(sa);
-                        else k_iter_stream<kStreamKH2, 2, false><<<grid, 128, 0, st>>>(sa);
+                        if (p->fast_math) launch_stream<kStreamKH2, 2, true>(sp.ppl, grid, 128, st, sa);
+                        else launch_stream<kStreamKH2, 2, false>(sp.ppl, grid, 128, st, sa);
                     } else {
-                        if (p->fast_math) k_iter_stream<kStreamK1, 1, true><<<grid, 64, 0, st>>>(sa);
-                        else k_iter_stream<kStreamK1, 1, false><<<grid, 64, 0, st>>>(sa);
+                        if (p->fast_math) launch_stream<kStreamK1, 1, true>(sp.ppl, grid, 64, st, sa);
+                        else launch_stream<kStreamK1, 1, false>(sp.ppl, grid, 64, st, sa);
                     }
                     cur ^= 1;
                     it += sa.K;
@@ -2015,7 +2123,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
             const dim3 g(va_cdiv(P.ws[s - 1] * P.hs[s - 1], TPB), P.NP);
             k_upsample<<<g, TPB, 0, st>>>(state[0], state[1], eps ? sel : nullptr, cur, lw, lh, lp, plane, ro, P.ws[s - 1],
                                            P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1], 1.0f / p->scale_step, perm);
-            const int fperm = level_kernel(p, eps, s - 1, P.ws[s - 1], P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1], nullptr) != LK_TILE ? 0 : 1;
+            const int fperm = P.lk[s - 1] != LK_TILE ? 0 : 1;
             const dim3 gi(va_cdiv(P.pitch[s - 1] * P.hs[s - 1], TPB), P.NP);
             k_level_init<<<gi, TPB, 0, st>>>(ro, state[0], P.ws[s - 1], P.hs[s - 1], P.pitch[s - 1], P.plane[s - 1], fperm);
             VA_LAUNCH_CHECK();
@@ -2026,7 +2134,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
     {
         const dim3 g(va_cdiv(w * h, TPB), P.NP);
         k_flow_out<<<g, TPB, 0, st>>>(state[0], state[1], eps ? sel : nullptr, cur, w, h, P.pitch[0], P.plane[0], (float*)flow,
-                                       level_kernel(p, eps, 0, w, h, P.pitch[0], P.plane[0], nullptr) != LK_TILE ? 0 : 1);
+                                       P.lk[0] != LK_TILE ? 0 : 1);
         VA_LAUNCH_CHECK();
     }
     return VA_OK;
