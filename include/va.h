@@ -168,8 +168,8 @@ typedef struct va_tvl1_params {
        pair; levels of at most 256 columns, fixed-iteration mode). */
     int rows_levels;   /* -1 (default): the library decides per level; otherwise a bit set as stream_levels: bit s =
                           level s iterates with k_iter_rows where it applies (takes precedence over stream_levels) */
-    int stream_ppl;    /* 0 (default): pixels per lane of the row pipeline chosen per level (3 where a level of 129..192 columns
-                          then is ONE 192-column strip, else 2); 2, 3, 4 force it (strips of 128 / 192 / 256 columns) */
+    int stream_ppl;    /* 0 or 2 (default): the row pipeline keeps 2 pixels per lane (128-column strips); 3: 192-column strips
+                          (a 129..192-column level then is one strip without x halo; measured no faster) */
     int rows_cfg;      /* 0 (default): the library's pipeline shape; otherwise waves * 16 + levels per wave (one of the
                           compiled shapes: 4x4, 2x8, 3x5, 4x3, 8x2, 2x6), i.e. waves x levels iterations per pass */
 } va_tvl1_params;
@@ -181,7 +181,7 @@ int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* h
 
 /* The register tiling va_tvl1_flow will use, level by level (host logic; HOST array of >= 6*16 ints): per level
  * { tile width, tile height, waves per workgroup, block depth K, tiles in x, tiles in y }; a level that streams
- * reports { strip width (64 x pixels per lane: 128, 192 or 256), 0 (rows stream through), waves of the row pipeline (2 or 1), iterations per pass
+ * reports { strip width (64 x pixels per lane: 128 or 192), 0 (rows stream through), waves of the row pipeline (2 or 1), iterations per pass
  * (16 with two waves, 10 with one), strips in x, 0 (chunks of rows: chosen per call from the number of pairs) }.
  * Returns the number of levels (0 on bad arguments). */
 int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out);

@@ -70,9 +70,15 @@ def test_tile_plan_of_the_benchmark_pyramid():
     224x224 benchmark pyramid in fixed-iteration mode, and the epsilon mode's forced block depth 1."""
     from video_analytics_amd import _ffi, flow
     plan = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0))
-    # the 224^2 level streams (two 128-column strips, two waves, 16 iterations per pass); the levels below use register tiles
-    assert (plan[0]["tile_w"], plan[0]["tile_h"], plan[0]["waves"], plan[0]["block_iters"], plan[0]["tiles_x"]) == (128, 0, 2, 16, 2)
-    assert [d["tile_h"] > 0 for d in plan[1:]] == [True] * 4
+    # the 224^2, 179^2 (two 128-column strips each) and 114^2 (one strip) levels stream (two waves, 16 iterations per pass);
+    # 143^2 (strips 56 % full) and 91^2 (too few jobs) iterate on 64x64 register tiles -- the measured choice
+    assert [(d["tile_w"], d["tile_h"], d["waves"], d["block_iters"], d["tiles_x"]) for d in plan] == [
+        (128, 0, 2, 16, 2), (128, 0, 2, 16, 2), (64, 64, 4, 12, 3), (128, 0, 2, 16, 1), (64, 64, 4, 16, 2)]
+    rows = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 9))  # k_iter_rows: 4, 3, 3, 2, 2 px per lane
+    assert [(d["tile_w"], d["tile_h"], d["waves"], d["block_iters"]) for d in rows] == [(256, 0, 4, 16), (192, 0, 4, 16), (192, 0, 4, 16),
+                                                                                          (128, 0, 4, 16), (128, 0, 4, 16)]
+    ppl3 = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 8, stream_ppl=3))
+    assert [(d["tile_w"], d["block_iters"], d["tiles_x"]) for d in ppl3] == [(192, 10, 2), (192, 10, 1), (192, 10, 1), (192, 10, 1), (192, 10, 1)]
     everywhere = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 8))
     assert [(d["tile_w"], d["tiles_x"]) for d in everywhere] == [(128, 2), (128, 2), (128, 2), (128, 1), (128, 1)]
     hd = flow.tile_plan(1280, 720, _ffi.default_tvl1_params(epsilon=0.0))  # wide levels: one wave, 10 per pass, halo 10

@@ -82,6 +82,20 @@ def test_streaming_kernel_bit_exact(oracle_tvl1, H, W, nch):
         assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("ppl", [2, 3])
+@pytest.mark.parametrize("H,W,nch", [(179, 179, 0), (143, 143, 2), (100, 64, 3), (64, 300, 1), (150, 400, 3), (57, 131, 1), (33, 190, 1),
+                                     (129, 225, 2), (40, 700, 1), (16, 16, 0)])
+def test_streaming_kernel_pixels_per_lane_bit_exact(oracle_tvl1, ppl, H, W, nch):
+    # k_iter_stream with 2 and 3 pixels per lane (strips of 128 / 192 columns; a shallower pipeline for 3):
+    # one strip without halo (179, 143, 131 columns at 3 per lane), several strips with halos that are multiples of the
+    # pixels per lane, chunks of rows, ragged widths whose pitch is padded to a multiple of 12 for 3 per lane
+    gray = _frames(1, 3, H, W, seed=7 * H + W + ppl)
+    for iters, warps, nscales in ((10, 1, 1), (29, 2, 3)):
+        ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=warps, nscales=nscales, tile_mask=1 << 8,
+                             stream_chunks=nch, stream_ppl=ppl)
+        assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
 ROWS_SHAPES = [0, 4 * 16 + 4, 2 * 16 + 8, 3 * 16 + 5, 4 * 16 + 3, 8 * 16 + 2, 2 * 16 + 6]
 
 

@@ -133,6 +133,30 @@ def test_benchmark_batch_32_matches_oracle_on_every_row(weights3, c_in):
     m.close()
 
 
+def test_reference_classifier_traversal_runs_verbatim(weights3):
+    """The body of the reference's validate() forward (Sheet03/spatialModel.py:212-218), verbatim, over the mirror's
+    ``features`` / ``classifierList`` / ``classifierLen``: equal to forward() bit for bit."""
+    from video_analytics_amd.spatialModel import SpatialNetwork
+    w = {k: [t.clone() for t in v] for k, v in weights3.items()}
+    self = SpatialNetwork(101, 1, 0.1, 0.9, 256, None, None, [10, 20], None, gpu=True, weights=w)
+    ip = _inputs(3, 3, seed=19).cuda()
+    op = self.features(ip)
+    op = op.view(op.size(0), -1)
+    for cl in self.classifierList[:(self.classifierLen - 1)]:  # evaluate till second last layer
+        op = cl(op)
+    featureVectors = op  # keep the second last layer's output as the feature vector
+    for cl in self.classifierList[(self.classifierLen - 1):]:  # continue till last layer
+        op = cl(op)
+    _, desc, logits = self.model.forward(ip)
+    assert torch.equal(featureVectors, desc) and torch.equal(op, logits)
+    assert self.classifierLen == 10
+    with pytest.raises(ValueError):
+        self.classifierList[9](desc)  # not the tensor stage 8 handed out
+    with pytest.raises(ValueError):
+        self.classifierList[3](ip)
+    self.model.close()
+
+
 def test_bf16_stream_tracks_the_fp32_stream(weights3):
     """BASELINE config 5 (bf16 conv stack, fp32 accumulate/classifier): not a parity configuration -- the
     test states its deviation from the fp32 oracle: relative error of the class scores below 3e-2 of their

@@ -8,12 +8,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from video_analytics_amd import _ffi, flow as vflow
 
+if os.environ.get("VA_LIB_EXP"):
+    _ffi.LIB_PATH = os.path.abspath(os.environ["VA_LIB_EXP"])  # timing experiments with another build
+OVER = {a.split("=")[0]: int(a.split("=")[1]) for a in os.environ.get("TVL1_PARAMS", "").split(",") if a}
+
 NP = int(os.environ.get("PAIRS", "320"))
 NS = int(os.environ.get("STREAMS", "2"))
 SHAPES = {"4x4": 68, "2x8": 40, "3x5": 53, "4x3": 67, "8x2": 130, "2x6": 38}
 modes = sys.argv[1:] or ["tiles", "stream"] + ["rows:" + k for k in SHAPES]
 torch.manual_seed(0)
-for n in (224, 179, 143, 114, 91):
+for n in [int(x) for x in os.environ.get("SIZES", "224,179,143,114,91").split(",")]:
     fr = (torch.rand(NP, 2, n, n, device="cuda") * 255).to(torch.uint8)
     for mode in modes:
         kw = dict(stream_levels=0, rows_levels=0)
@@ -23,6 +27,7 @@ for n in (224, 179, 143, 114, 91):
             kw["rows_levels"] = 1
             if ":" in mode:
                 kw["rows_cfg"] = SHAPES[mode.split(":")[1]]
+        kw.update(OVER)
         p = _ffi.default_tvl1_params(epsilon=0.0, nscales=1, **kw)
         run = (lambda: vflow.tvl1_flow_concurrent(fr, p, NS)) if NS > 1 else (lambda: vflow.tvl1_flow(fr, p))
         run(); torch.cuda.synchronize()

@@ -334,9 +334,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef VA_REV
 #define VA_REV 1
 #endif
-#ifndef VA_STREAM_MIN_PX
-#define VA_STREAM_MIN_PX 40000.0  // smaller levels: too few strip x chunk jobs for the GPU, the register tiles win
-#endif
 #ifndef VA_STREAM_UNROLL2
 #define VA_STREAM_UNROLL2 1  // measured on the 224^2 level: 9.8 -> 9.3 ms per warp step of 320 pairs
 #endif
@@ -851,8 +848,8 @@ struct StreamArgs {
 // KH-1 out of a double-buffered LDS row instead of HBM and carries them through levels KH .. 2KH-1, so that one pass
 // over the strip is worth K <= 2 KH iterations of HBM traffic; both waves share the ring of per-warp constants; one
 // workgroup barrier per step keeps them a step apart.
-// PPL pixels per lane: a strip is 64 * PPL columns wide (2: 128, the layout the kernel was tuned on; 3: 192, so that a
-// 129..192-column level is ONE well-filled strip without any x halo; 4: 256).
+// PPL pixels per lane: a strip is 64 * PPL columns wide (2: 128, the default; 3: 192, so that a 129..192-column level is
+// ONE well-filled strip without any x halo -- a tested option that measured no faster, see stream_ppl()).
 template <int PPL, int KH, int NWV, bool FAST>
 __global__ void __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_iter_stream(StreamArgs a)
 {
@@ -1531,26 +1528,33 @@ void launch_iter(const TilePick& tp, const IterArgs& a, int npairs, hipStream_t 
 }
 
 // ---- k_iter_stream: strips x chunks of a level
-constexpr int kStreamK1 = 10;       // one-wave pipeline: iterations per pass
-constexpr int kStreamKH2 = 8;       // two-wave pipeline: levels per wave (16 iterations per pass)
+constexpr int kStreamK1 = 10;       // one-wave pipeline: iterations per pass (2 pixels per lane)
+constexpr int kStreamKH2 = 8;       // two-wave pipeline: levels per wave (16 iterations per pass; 2 pixels per lane)
+// A level keeps 6 x PPL registers per lane: with 3 pixels per lane the pipelines are shallower (5 levels per wave), so
+// that two waves per SIMD still fit the register file (8 and 6 levels spill, seen at compile time and in the timings)
+constexpr int stream_k1(int ppl) { return ppl == 2 ? kStreamK1 : 5; }
+constexpr int stream_kh2(int ppl) { return ppl == 2 ? kStreamKH2 : 5; }
 constexpr int kStreamBit = 1 << 8;  // va_tvl1_params.tile_mask bit: iterate with k_iter_stream
 struct StreamPick {
     int nsx, nch, R, HX, two, ppl;
 };
-// Pixels per lane of k_iter_stream on a level of width w: 3 (192-column strips) where that makes the level ONE strip
-// with no x halo (129 .. 192 columns: 179^2 fills 93 % of the lanes instead of 70 % of two 128-column strips), else 2.
-// va_tvl1_params.stream_ppl forces 2, 3 or 4.
+// Pixels per lane of k_iter_stream: 2 (128-column strips) unless va_tvl1_params.stream_ppl asks for 3 (192-column
+// strips: a 129..192-column level then is ONE strip without x halo -- 179^2 fills 93 % of the lanes instead of 70 % of
+// two 128-column strips).  Measured on the benchmark's 179^2 / 143^2 levels (320 pairs, two streams): 33.6 / 25.6 ms
+// with 3 per lane (best of 5 or 4 levels per wave and 2..4 chunks of rows) against 32.9 / 25.5 ms with 2: the better
+// fill is paid back by the shallower pipeline (6 x 3 registers per level: 10 instead of 16 iterations per pass) and by
+// half as many strip x chunk jobs.  So 2 stays the default; 3 is kept as a tested option.
 int stream_ppl(const va_tvl1_params* p, int w)
 {
-    if (p->stream_ppl >= 2 && p->stream_ppl <= 4) return p->stream_ppl;
-    return (w > 128 && w <= 192) ? 3 : 2;
+    (void)w;
+    return p->stream_ppl == 3 ? 3 : 2;
 }
-template <int KH, int NWV, bool FAST>
-void launch_stream(int ppl, dim3 grid, int threads, hipStream_t st, const StreamArgs& sa)
+template <bool TWO, bool FAST>
+void launch_stream(int ppl, dim3 grid, hipStream_t st, const StreamArgs& sa)
 {
-    if (ppl == 3) k_iter_stream<3, KH, NWV, FAST><<<grid, threads, 0, st>>>(sa);
-    else if (ppl == 4) k_iter_stream<4, KH, NWV, FAST><<<grid, threads, 0, st>>>(sa);
-    else k_iter_stream<2, KH, NWV, FAST><<<grid, threads, 0, st>>>(sa);
+    constexpr int NWV = TWO ? 2 : 1;
+    if (ppl == 3) k_iter_stream<3, TWO ? stream_kh2(3) : stream_k1(3), NWV, FAST><<<grid, NWV * 64, 0, st>>>(sa);
+    else k_iter_stream<2, TWO ? stream_kh2(2) : stream_k1(2), NWV, FAST><<<grid, NWV * 64, 0, st>>>(sa);
 }
 // Strips of a level.  Two-wave pipeline (16 iterations per pass) where the deeper x halo costs nothing, i.e. where the
 // level has no interior strip (w <= 224); wider levels use the one-wave pipeline (10 per pass, halo 10: measured on
@@ -1559,8 +1563,8 @@ void stream_strips(const va_tvl1_params* p, int w, StreamPick& sp)
 {
     sp.ppl = stream_ppl(p, w);
     const int SW = 64 * sp.ppl, hq = sp.ppl == 3 ? 3 : 2;  // strip origins stay multiples of the pixels per lane
-    sp.two = p->stream_waves != 1 && tiles_1d(w, SW, va_cdiv(2 * kStreamKH2, hq) * hq) <= 2;
-    sp.HX = va_cdiv(sp.two ? 2 * kStreamKH2 : kStreamK1, hq) * hq;
+    sp.two = p->stream_waves != 1 && tiles_1d(w, SW, va_cdiv(2 * stream_kh2(sp.ppl), hq) * hq) <= 2;
+    sp.HX = va_cdiv(sp.two ? 2 * stream_kh2(sp.ppl) : stream_k1(sp.ppl), hq) * hq;
     sp.nsx = tiles_1d(w, SW, sp.HX);
 }
 StreamPick pick_stream(const va_tvl1_params* p, int w, int h, int npairs)
@@ -1579,9 +1583,8 @@ StreamPick pick_stream(const va_tvl1_params* p, int w, int h, int npairs)
     sp.nch = va_cdiv(h, sp.R);
     return sp;
 }
-// Level (w, h) of the pyramid iterates with k_iter_stream: wherever its 128-column strips are well filled and the level
-// is large enough for a GPU-full of strip x chunk jobs (measured, tools/bench_tvl1_levels.py: 224^2 and every level of
-// the 1280x720 pyramid win, 179^2 and below lose to the register tiles).  tile_mask bit 8 forces it (tests);
+// Level (w, h) of the pyramid iterates with k_iter_stream: wherever its strips are well filled and the level is large
+// enough for a GPU-full of strip x chunk jobs (measured, tools/bench_tvl1_levels.py).  tile_mask bit 8 forces it (tests);
 // va_tvl1_params.stream_levels >= 0 is the explicit per-level choice (bit s = level s, 0 = never).
 bool level_streams(const va_tvl1_params* p, bool eps, int s, int w, int h, size_t plane)
 {
@@ -1591,7 +1594,11 @@ bool level_streams(const va_tvl1_params* p, bool eps, int s, int w, int h, size_
     if (p->stream_levels >= 0) return ((p->stream_levels >> s) & 1) != 0;
     StreamPick sp{};
     stream_strips(p, w, sp);
-    return (double)w >= 0.75 * 64.0 * sp.ppl * sp.nsx && (double)w * h >= VA_STREAM_MIN_PX;
+    // measured per level of the 224x224 pyramid (320 pairs, two streams; profiles/README.md): the row pipeline wins on 224^2
+    // (two strips 88 % full), 179^2 (70 %) and 114^2 (one strip, 89 %), the register tiles on 143^2 (56 %) and 91^2 (71 %
+    // of one strip, too few jobs); every level of the 1280x720 pyramid (80..85 %) streams
+    const double fill = (double)w / (64.0 * sp.ppl * sp.nsx), px = (double)w * h;
+    return (fill >= 0.85 && px >= 10000.0) || (fill >= 0.69 && px >= 30000.0);
 }
 
 // ---- k_iter_rows: which levels, which pipeline shape
@@ -1746,7 +1753,7 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
     VA_CHECK_ARG(p->tile_mask >= 0 && p->tile_mask < (1 << (kNumCfgs + 2)), "va_tvl1: tile_mask must be in [0, %d]", (1 << (kNumCfgs + 2)) - 1);
     VA_CHECK_ARG(p->rows_levels >= -1 && p->rows_levels < (1 << kMaxScales) && p->rows_cfg >= 0 && p->rows_cfg < 256,
                  "va_tvl1: rows_levels must be -1 or a level bit set, rows_cfg in [0,255]");
-    VA_CHECK_ARG(p->stream_ppl == 0 || (p->stream_ppl >= 2 && p->stream_ppl <= 4), "va_tvl1: stream_ppl must be 0 (automatic), 2, 3 or 4");
+    VA_CHECK_ARG(p->stream_ppl == 0 || p->stream_ppl == 2 || p->stream_ppl == 3, "va_tvl1: stream_ppl must be 0 (default), 2 or 3");
     VA_CHECK_ARG(p->stream_levels >= -1 && p->stream_levels < (1 << kMaxScales) && (p->stream_waves == 0 || p->stream_waves == 1) &&
                      p->stream_chunks >= 0 && p->stream_slots >= 0,
                  "va_tvl1: stream_levels must be -1 or a level bit set, stream_waves 0 or 1, stream_chunks and stream_slots >= 0");
@@ -1872,7 +1879,7 @@ extern "C" int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out
         if (lk == LK_STREAM) {
             StreamPick sp{};
             stream_strips(p, ws[s], sp);
-            const int plan[6] = {64 * sp.ppl, 0, sp.two ? 2 : 1, sp.two ? 2 * kStreamKH2 : kStreamK1, sp.nsx, 0};
+            const int plan[6] = {64 * sp.ppl, 0, sp.two ? 2 : 1, sp.two ? 2 * stream_kh2(sp.ppl) : stream_k1(sp.ppl), sp.nsx, 0};
             memcpy(out + 6 * s, plan, sizeof(plan));
             continue;
         }
@@ -2065,17 +2072,18 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                 const bool two = sp.two != 0;
                 for (int it = 0; it < p->iters;) {
                     const int rem = p->iters - it;
-                    const bool w2 = two && rem > kStreamKH2;  // the two-wave kernel needs its last level in the second wave
-                    sa.K = w2 ? (rem < 2 * kStreamKH2 ? rem : 2 * kStreamKH2) : (rem < kStreamK1 ? rem : kStreamK1);
+                    const int kh2 = stream_kh2(sp.ppl), k1 = stream_k1(sp.ppl);
+                    const bool w2 = two && rem > kh2;  // the two-wave kernel needs its last level in the second wave
+                    sa.K = w2 ? (rem < 2 * kh2 ? rem : 2 * kh2) : (rem < k1 ? rem : k1);
                     sa.sin = state[cur];
                     sa.sout = state[cur ^ 1];
                     sa.rev = VA_REV ? (launches & 1) : 0;
                     if (w2) {
-                        if (p->fast_math) launch_stream<kStreamKH2, 2, true>(sp.ppl, grid, 128, st, sa);
-                        else launch_stream<kStreamKH2, 2, false>(sp.ppl, grid, 128, st, sa);
+                        if (p->fast_math) launch_stream<true, true>(sp.ppl, grid, st, sa);
+                        else launch_stream<true, false>(sp.ppl, grid, st, sa);
                     } else {
-                        if (p->fast_math) launch_stream<kStreamK1, 1, true>(sp.ppl, grid, 64, st, sa);
-                        else launch_stream<kStreamK1, 1, false>(sp.ppl, grid, 64, st, sa);
+                        if (p->fast_math) launch_stream<false, true>(sp.ppl, grid, st, sa);
+                        else launch_stream<false, false>(sp.ppl, grid, st, sa);
                     }
                     cur ^= 1;
                     it += sa.K;

@@ -105,6 +105,8 @@ class SpatialNetwork(object):
         self.ckpLoc = ckpLoc if ckpLoc is None or ckpLoc.endswith("/") else ckpLoc + "/"
         self.features = self.model.features
         self.classify = self.model.classify
+        self.classifierList = self.model.classifier_list()  # the reference's indexable surface (:128-129), over the fused head
+        self.classifierLen = len(self.classifierList)
         self.trainDict = {}
         self.testDict = {}
         self.testMeters = fusion.DescriptorMeters(descriptorDim, self.device)  # persists across epochs (quirk 7)

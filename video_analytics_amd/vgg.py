@@ -173,6 +173,20 @@ class Vgg16Stream(object):
         return desc, logits
 
 
+    def classifier_list(self):
+        """The indexable ``self.classifierList`` of the reference (``list(self.model.classifier)``: Linear, ReLU, Dropout,
+        Linear, ReLU, Dropout, Linear, ReLU, Dropout, Linear; Sheet03/spatialModel.py:128-129) as ten callables, so that
+        the reference's own traversal runs unchanged over the fused kernels:
+
+            op = self.features(ip); op = op.view(op.size(0), -1)
+            for cl in self.classifierList[:9]: op = cl(op)      # -> featureVectors [B, D]
+            for cl in self.classifierList[9:]: op = cl(op)      # -> class scores   [B, nClasses]
+
+        Stage 0 runs the whole classifier (``va_vgg16_classify``) on the flattened features, stages 1..7 hand its result
+        on, stage 8 returns the descriptor tensor, stage 9 returns the scores that belong to exactly that tensor (any
+        other input raises ``ValueError``: the stages are one fused operator, not ten independent modules)."""
+        return [_ClassifierStage(self, i) for i in range(10)]
+
     # ---- training (SURVEY section 8f rank 4; fp32 models only) ----
 
     def train_init(self):
@@ -295,6 +309,39 @@ def state_dict_from_weights(weights, prefix="module."):
         sd["%sclassifier.%d.weight" % (prefix, k)] = weights["fc_w"][i]
         sd["%sclassifier.%d.bias" % (prefix, k)] = weights["fc_b"][i]
     return sd
+
+
+class _FusedHead(object):
+    """What flows between the stages of ``classifier_list()``: both outputs of the fused classifier."""
+
+    def __init__(self, desc, logits):
+        self.desc, self.logits = desc, logits
+
+
+class _ClassifierStage(object):
+    def __init__(self, stream, index):
+        self.stream, self.index = stream, index
+
+    def __call__(self, op):
+        st = self.stream
+        if self.index == 0:
+            if not isinstance(op, torch.Tensor) or op.dim() != 2 or op.shape[1] != 512 * 7 * 7:
+                raise ValueError("classifierList[0]: expected the flattened features [B, 25088]")
+            desc, logits = st.classify(op.reshape(op.shape[0], 512, 7, 7))
+            return _FusedHead(desc, logits)
+        if self.index < 8:
+            if not isinstance(op, _FusedHead):
+                raise ValueError("classifierList[%d]: apply the stages in order, starting from classifierList[0]" % self.index)
+            return op
+        if self.index == 8:
+            if not isinstance(op, _FusedHead):
+                raise ValueError("classifierList[8]: apply the stages in order, starting from classifierList[0]")
+            st._head = (op.desc, op.logits)
+            return op.desc
+        head = getattr(st, "_head", None)
+        if head is None or op is not head[0]:
+            raise ValueError("classifierList[9]: expected the descriptor tensor classifierList[8] returned")
+        return head[1]
 
 
 def _ffi_conv_cout(i):
