@@ -103,7 +103,10 @@ def main(prefix, out):
                     dur[name] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
         gui = sum(v.get("GRBM_GUI_ACTIVE", 0.0) for v in agg.values())
         tot = sum(dur.values())
-        valu = {"tvl1_hip_blob": stamp, "steps_profiled": steps, "clock_ghz": (gui / 8.0 / tot / 1e9) if tot else 2.3,
+        # GRBM_GUI_ACTIVE / 8 / duration reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS): the
+        # quotient is recorded as measured, the issue capacity is priced at no more than the 2.4 GHz maximum clock
+        clk = (gui / 8.0 / tot / 1e9) if tot else 2.4
+        valu = {"tvl1_hip_blob": stamp, "steps_profiled": steps, "clock_ghz_gui_quotient": clk, "clock_ghz": min(clk, 2.4),
                 "units": "SQ_INSTS_VALU: wave-instructions; SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES: quad-cycles; summed over the profiled run "
                          "(kernels are serialised under --pmc); px_iters: pixel-iterations of the kernel over the same run",
                 "kernels": {k: dict(SQ_INSTS_VALU=v.get("SQ_INSTS_VALU", 0.0), SQ_ACTIVE_INST_VALU=v.get("SQ_ACTIVE_INST_VALU", 0.0),
