@@ -88,7 +88,12 @@ def pmc_blocks(cfg, busy_ms_per_step, px_iters_per_step, launches_per_step):
         busy = sum(x["SQ_ACTIVE_INST_VALU"] for k, x in v["kernels"].items() if k.startswith("k_iter")) * 4.0 / steps  # quad-cycles
         clock_ghz = float(v.get("clock_ghz", 2.3))
         cap = N_SIMD * clock_ghz * 1e9 / 4.0  # wave-instructions per second the chip can issue (one per SIMD per 4 cycles)
+        # the least the arithmetic needs: 59 vector instructions per level-row of 128 pixels in the row pipeline's steady
+        # loop (2 pixels per lane, packed math) = 0.461 wave-instructions per pixel-iteration
+        min_instr = 59.0 / 128.0
         valu = dict(wave_instr_per_px_iter=insts / px_iters_per_step, wave_instr_per_step=insts,
+                    wave_instr_per_px_iter_min=min_instr,
+                    frac_min_work=min_instr * px_iters_per_step / cap / (busy_ms_per_step * 1e-3),
                     issue_capacity_G_per_s=cap / 1e9, clock_ghz=clock_ghz,
                     frac_useful=insts / cap / (busy_ms_per_step * 1e-3),
                     frac_busy=busy / (N_SIMD * clock_ghz * 1e9) / (busy_ms_per_step * 1e-3),

@@ -39,15 +39,21 @@ def kernel_key(name, grid):
 
 
 def counters(dirname):
-    f = glob.glob(os.path.join(dirname, "*", "*_counter_collection.csv"))
-    return list(csv.DictReader(open(f[0]))) if f else []
+    f = newest(os.path.join(dirname, "*", "*_counter_collection.csv"))
+    return list(csv.DictReader(open(f))) if f else []
+
+
+def newest(pattern):
+    """gpurun merges a call's files INTO the local directory: an earlier call's CSVs may still be there."""
+    f = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return f[-1] if f else None
 
 
 def main(prefix, out):
     os.makedirs(out, exist_ok=True)
     stamp = git_blob_hash(TVL1_SRC)
-    shutil.copy(glob.glob(os.path.join(prefix, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(out, "bench_kernel_stats.csv"))
-    shutil.copy(glob.glob(os.path.join(prefix, "trace", "*", "*_domain_stats.csv"))[0], os.path.join(out, "bench_domain_stats.csv"))
+    shutil.copy(newest(os.path.join(prefix, "trace", "*", "*_kernel_stats.csv")), os.path.join(out, "bench_kernel_stats.csv"))
+    shutil.copy(newest(os.path.join(prefix, "trace", "*", "*_domain_stats.csv")), os.path.join(out, "bench_domain_stats.csv"))
     for src, dst in (("bench.log", "bench_default.json"), ("trace_bench.log", "bench_under_rocprof.json")):
         json.dump(bench_line(os.path.join(prefix, src)), open(os.path.join(out, dst), "w"), indent=1)
     cfg = bench_line(os.path.join(prefix, "bench.log"))["config"]
@@ -96,8 +102,8 @@ def main(prefix, out):
             kind = "k_iter_tile" if lv["tile_h"] else ("k_iter_rows" if lv["tiles_x"] == 1 and lv["tile_w"] != 128 else "k_iter_stream")
             pxit[kind] += 320.0 * w_ * h_ * 1500
         dur = collections.defaultdict(float)
-        tr = glob.glob(os.path.join(prefix, "pmc_sq", "*", "*_kernel_trace.csv"))
-        for r in (csv.DictReader(open(tr[0])) if tr else []):
+        tr = newest(os.path.join(prefix, "pmc_sq", "*", "*_kernel_trace.csv"))
+        for r in (csv.DictReader(open(tr)) if tr else []):
             for name in ("k_iter_stream", "k_iter_tile", "k_iter_rows"):
                 if name in r["Kernel_Name"]:
                     dur[name] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
@@ -120,7 +126,7 @@ def main(prefix, out):
                       % (k, v["SQ_INSTS_VALU"] / v["px_iters"], 4.0 * v["SQ_ACTIVE_INST_VALU"] / max(v["SQ_INSTS_VALU"], 1.0), valu["clock_ghz"]))
 
     # ---- kernel trace grouped by kernel and grid
-    rows = list(csv.DictReader(open(glob.glob(os.path.join(prefix, "trace", "*", "*_kernel_trace.csv"))[0])))
+    rows = list(csv.DictReader(open(newest(os.path.join(prefix, "trace", "*", "*_kernel_trace.csv")))))
     agg = collections.defaultdict(list)
     for r in rows:
         n_ = r["Kernel_Name"]
