@@ -92,7 +92,10 @@ size_t va_vgg16_workspace_bytes(const va_vgg16* model, int batch);
  * A/B and test switches of ONE model handle (defaults are the measured choices of DESIGN.md; results of the
  * fp32 path do not depend on VA_OPT_F32_CONV_KERNEL, the three bf16 variants are bit-identical to each other):
  *   VA_OPT_BF16_VARIANT     0 (default) tile and staging scheme chosen per layer; 1 = 64-channel tiles with one
- *                           LDS buffer on every layer; 2 = the LDS-DMA ring on every layer
+ *                           LDS buffer on every layer; 2 = the LDS-DMA ring on every layer; 3 / 4 = the halo-brick
+ *                           kernel on the layers of 28x28 pixels and more (8 waves with 64-pixel wave tiles / 4 waves
+ *                           with 128-pixel wave tiles; chunk-major K order: another fp32 summation order, so within
+ *                           bf16 noise of 0..2 rather than bit-identical; measured no faster)
  *   VA_OPT_F32_CONV_KERNEL  1 (default) LDS-DMA staged fp32 kernel where Cin % 32 == 0; 0 = register-staged kernel
  *   VA_OPT_TRAIN_STOP_AT    -1 (default) full training step; i in [0,12]: va_vgg16_train_step returns
  *                           VA_ERR_STOPPED after the backward pass of conv layer i, leaving the gradient buffers
@@ -161,7 +164,8 @@ typedef struct va_tvl1_params {
     int stream_levels; /* -1 (default): the library decides per level; otherwise a bit set: bit s = pyramid level s
                           (0 = full resolution) iterates with the row pipeline, every other level on the register tiles */
     int stream_waves;  /* 0 (default): two-wave pipeline (16 iterations per pass) where a level has at most two strips,
-                          one-wave (10 per pass) elsewhere; 1: one-wave pipeline everywhere */
+                          one-wave (10 per pass) elsewhere; 1: one-wave pipeline everywhere; 3: where the two-wave
+                          pipeline would run, ONE wave with all 16 levels and a whole SIMD's registers (measured slower) */
     int stream_chunks; /* 0 (default): rows cut into as many chunks as fill the GPU; n > 0: n chunks (capped at h/32) */
     int stream_slots;  /* 0 (default): target number of strip x chunk x pair jobs per call (640 two-wave / 1024 one-wave) */
     /* The persistent row pipeline (k_iter_rows: all `iters` iterations of a warp step in one launch, one workgroup per

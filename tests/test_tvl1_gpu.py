@@ -96,6 +96,16 @@ def test_streaming_kernel_pixels_per_lane_bit_exact(oracle_tvl1, ppl, H, W, nch)
         assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("H,W,nch", [(224, 224, 0), (100, 64, 3), (129, 225, 2), (57, 131, 1), (179, 179, 2)])
+def test_streaming_kernel_one_deep_wave_bit_exact(oracle_tvl1, H, W, nch):
+    # stream_waves = 3: ONE wave carries all 16 levels (whole register file of its SIMD, no hand-over, no barrier)
+    gray = _frames(1, 3, H, W, seed=H + 3 * W)
+    for iters, warps, nscales in ((10, 1, 1), (37, 2, 3)):
+        ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=warps, nscales=nscales, tile_mask=1 << 8,
+                             stream_chunks=nch, stream_waves=3)
+        assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
 ROWS_SHAPES = [0, 4 * 16 + 4, 2 * 16 + 8, 3 * 16 + 5, 4 * 16 + 3, 8 * 16 + 2, 2 * 16 + 6]
 
 

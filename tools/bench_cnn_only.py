@@ -6,6 +6,10 @@ import torch
 from video_analytics_amd import pipeline, synth
 dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
 pipe = pipeline.TwoStreamPipeline(device=0, cnn_dtype=dtype)
+if len(sys.argv) > 2:  # python tools/bench_cnn_only.py bf16 <VA_OPT_BF16_VARIANT>
+    from video_analytics_amd import _ffi
+    for m in (pipe.spatial, pipe.temporal):
+        m.set_option(_ffi.VA_OPT_BF16_VARIANT, int(sys.argv[2]))
 rgb, gray, _ = synth.synth_clips(32, seed=0)
 rgb = rgb.cuda(); stack = torch.randn(32, 20, 224, 224, device='cuda')
 for _ in range(2): pipe.run_batch(rgb, flow_stack=stack)

@@ -851,7 +851,8 @@ struct StreamArgs {
 // PPL pixels per lane: a strip is 64 * PPL columns wide (2: 128, the default; 3: 192, so that a 129..192-column level is
 // ONE well-filled strip without any x halo -- a tested option that measured no faster, see stream_ppl()).
 template <int PPL, int KH, int NWV, bool FAST>
-__global__ void __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_iter_stream(StreamArgs a)
+__global__ void __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV == 1 && KH > 10) ? 1 : 2, (NWV == 1 && KH > 10) ? 1 : 2)))
+k_iter_stream(StreamArgs a)
 {
     typedef Row<PPL> R;
     constexpr int NP = R::NP, NT = R::NT, SW = 64 * PPL;
@@ -1536,7 +1537,7 @@ constexpr int stream_k1(int ppl) { return ppl == 2 ? kStreamK1 : 5; }
 constexpr int stream_kh2(int ppl) { return ppl == 2 ? kStreamKH2 : 5; }
 constexpr int kStreamBit = 1 << 8;  // va_tvl1_params.tile_mask bit: iterate with k_iter_stream
 struct StreamPick {
-    int nsx, nch, R, HX, two, ppl;
+    int nsx, nch, R, HX, two, ppl, deep1;
 };
 // Pixels per lane of k_iter_stream: 2 (128-column strips) unless va_tvl1_params.stream_ppl asks for 3 (192-column
 // strips: a 129..192-column level then is ONE strip without x halo -- 179^2 fills 93 % of the lanes instead of 70 % of
@@ -1564,6 +1565,9 @@ void stream_strips(const va_tvl1_params* p, int w, StreamPick& sp)
     sp.ppl = stream_ppl(p, w);
     const int SW = 64 * sp.ppl, hq = sp.ppl == 3 ? 3 : 2;  // strip origins stay multiples of the pixels per lane
     sp.two = p->stream_waves != 1 && tiles_1d(w, SW, va_cdiv(2 * stream_kh2(sp.ppl), hq) * hq) <= 2;
+    // stream_waves == 3 (experiment): where the two-wave pipeline would run, ONE wave with all 16 levels and the whole
+    // register file of its SIMD (no hand-over, no barrier)
+    sp.deep1 = sp.two && p->stream_waves == 3 && sp.ppl == 2;
     sp.HX = va_cdiv(sp.two ? 2 * stream_kh2(sp.ppl) : stream_k1(sp.ppl), hq) * hq;
     sp.nsx = tiles_1d(w, SW, sp.HX);
 }
@@ -1754,7 +1758,7 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
     VA_CHECK_ARG(p->rows_levels >= -1 && p->rows_levels < (1 << kMaxScales) && p->rows_cfg >= 0 && p->rows_cfg < 256,
                  "va_tvl1: rows_levels must be -1 or a level bit set, rows_cfg in [0,255]");
     VA_CHECK_ARG(p->stream_ppl == 0 || p->stream_ppl == 2 || p->stream_ppl == 3, "va_tvl1: stream_ppl must be 0 (default), 2 or 3");
-    VA_CHECK_ARG(p->stream_levels >= -1 && p->stream_levels < (1 << kMaxScales) && (p->stream_waves == 0 || p->stream_waves == 1) &&
+    VA_CHECK_ARG(p->stream_levels >= -1 && p->stream_levels < (1 << kMaxScales) && (p->stream_waves == 0 || p->stream_waves == 1 || p->stream_waves == 3) &&
                      p->stream_chunks >= 0 && p->stream_slots >= 0,
                  "va_tvl1: stream_levels must be -1 or a level bit set, stream_waves 0 or 1, stream_chunks and stream_slots >= 0");
     VA_CHECK_ARG(p->tau / p->theta <= 1000.0f && p->lambda * p->theta <= 1000.0f, "va_tvl1: tau/theta and lambda*theta must be <= 1000");
@@ -2073,12 +2077,14 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                 for (int it = 0; it < p->iters;) {
                     const int rem = p->iters - it;
                     const int kh2 = stream_kh2(sp.ppl), k1 = stream_k1(sp.ppl);
-                    const bool w2 = two && rem > kh2;  // the two-wave kernel needs its last level in the second wave
-                    sa.K = w2 ? (rem < 2 * kh2 ? rem : 2 * kh2) : (rem < k1 ? rem : k1);
+                    const bool w2 = two && rem > kh2 && !sp.deep1;  // the two-wave kernel needs its last level in the second wave
+                    sa.K = sp.deep1 ? (rem < 16 ? rem : 16) : w2 ? (rem < 2 * kh2 ? rem : 2 * kh2) : (rem < k1 ? rem : k1);
                     sa.sin = state[cur];
                     sa.sout = state[cur ^ 1];
                     sa.rev = VA_REV ? (launches & 1) : 0;
-                    if (w2) {
+                    if (sp.deep1) {
+                        k_iter_stream<2, 16, 1, false><<<grid, 64, 0, st>>>(sa);
+                    } else if (w2) {
                         if (p->fast_math) launch_stream<true, true>(sp.ppl, grid, st, sa);
                         else launch_stream<true, false>(sp.ppl, grid, st, sa);
                     } else {
