@@ -851,8 +851,9 @@ struct StreamArgs {
 // PPL pixels per lane: a strip is 64 * PPL columns wide (2: 128, the default; 3: 192, so that a 129..192-column level is
 // ONE well-filled strip without any x halo -- a tested option that measured no faster, see stream_ppl()).
 template <int PPL, int KH, int NWV, bool FAST>
-__global__ void __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu((NWV == 1 && KH > 10) ? 1 : 2, (NWV == 1 && KH > 10) ? 1 : 2)))
-k_iter_stream(StreamArgs a)
+__global__ void __launch_bounds__(NWV * 64)
+    __attribute__((amdgpu_waves_per_eu((NWV == 1 && KH > 10) ? 1 : 2, (NWV == 1 && KH > 10) ? 1 : 2)))
+    k_iter_stream(StreamArgs a)
 {
     typedef Row<PPL> R;
     constexpr int NP = R::NP, NT = R::NT, SW = 64 * PPL;
@@ -1568,6 +1569,9 @@ void stream_strips(const va_tvl1_params* p, int w, StreamPick& sp)
     // stream_waves == 3 (experiment): where the two-wave pipeline would run, ONE wave with all 16 levels and the whole
     // register file of its SIMD (no hand-over, no barrier)
     sp.deep1 = sp.two && p->stream_waves == 3 && sp.ppl == 2;
+    // (Also measured, round 2, and removed again: THREE waves of 4 / 5 levels each -- 12 / 15 iterations per pass at 144 /
+    // 168 registers, i.e. three resident waves per SIMD instead of two: 45.2 / 43.9 ms on the 224^2 level and 35.3 / 34.8
+    // on 179^2 against 41.6 / 32.9 for the two-wave form: more resident waves do not fill the idle issue slots.)
     sp.HX = va_cdiv(sp.two ? 2 * stream_kh2(sp.ppl) : stream_k1(sp.ppl), hq) * hq;
     sp.nsx = tiles_1d(w, SW, sp.HX);
 }
