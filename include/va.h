@@ -174,6 +174,10 @@ typedef struct va_tvl1_params {
                           level s iterates with k_iter_rows where it applies (takes precedence over stream_levels) */
     int stream_ppl;    /* 0 or 2 (default): the row pipeline keeps 2 pixels per lane (128-column strips); 3: 192-column strips
                           (a 129..192-column level then is one strip without x halo; measured no faster) */
+    int stream_queue;  /* 0 (default): the library decides; 1: the row pipeline runs ALL passes of a warp step in one launch,
+                          persistent workgroups pulling (pass, pair, strip, chunk) tasks from a queue, a pair's next pass
+                          starting as soon as that pair's previous pass is complete (k_iter_stream_q; stream_slots then is
+                          the number of persistent workgroups; bit-exact, measured slower); 2: one launch per pass */
     int rows_cfg;      /* 0 (default): the library's pipeline shape; otherwise waves * 16 + levels per wave (one of the
                           compiled shapes: 4x4, 2x8, 3x5, 4x3, 8x2, 2x6), i.e. waves x levels iterations per pass */
 } va_tvl1_params;

@@ -19,7 +19,7 @@ def _frames(n_seq, n_frames, H, W, seed):
 
 
 # tuning fields of va_tvl1_params the oracle has no counterpart for (results must not depend on them)
-PRODUCT_ONLY = ("block_iters", "tile_mask", "stream_levels", "stream_waves", "stream_chunks", "stream_slots", "stream_ppl", "rows_levels", "rows_cfg")
+PRODUCT_ONLY = ("block_iters", "tile_mask", "stream_levels", "stream_waves", "stream_chunks", "stream_slots", "stream_ppl", "stream_queue", "rows_levels", "rows_cfg")
 
 
 def _run_both(oracle_tvl1, gray, **kw):
@@ -104,6 +104,30 @@ def test_streaming_kernel_one_deep_wave_bit_exact(oracle_tvl1, H, W, nch):
         ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=warps, nscales=nscales, tile_mask=1 << 8,
                              stream_chunks=nch, stream_waves=3)
         assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
+@pytest.mark.parametrize("H,W,nch,slots", [(224, 224, 0, 0), (224, 224, 2, 3), (100, 64, 3, 2), (129, 225, 2, 7), (57, 131, 1, 1), (179, 179, 2, 0),
+                                           (114, 114, 3, 5)])
+def test_queued_row_pipeline_bit_exact(oracle_tvl1, H, W, nch, slots):
+    # stream_queue = 1: k_iter_stream_q runs all passes of a warp step in ONE launch; persistent workgroups pull (pass,
+    # pair, strip, chunk) tasks, a pair's next pass starting when that pair's previous pass is complete (per-pair
+    # counters, agent-scope release / acquire between workgroups).  Few persistent workgroups (1..7: every hand-over is
+    # between different tasks of the same few workgroups) as well as the default; 28 = 16 + 12 and 44 = 16 + 16 + 12
+    # iterations are queued, 20 = 16 + 4 is not (its last pass could not end in the second wave) and takes the
+    # launch-per-pass path; three pairs so that pairs overtake each other
+    gray = _frames(3, 2, H, W, seed=H + 5 * W)
+    for iters, warps, nscales in ((28, 2, 1), (44, 2, 3), (20, 1, 2)):
+        ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=warps, nscales=nscales, tile_mask=1 << 8,
+                             stream_chunks=nch, stream_queue=1, stream_slots=slots)
+        assert np.array_equal(out, ref), "iters %d: max abs diff %g" % (iters, np.abs(out - ref).max())
+
+
+def test_queued_row_pipeline_full_schedule(oracle_tvl1):
+    from video_analytics_amd import flow as vflow
+    gray = _frames(4, 3, 224, 224, seed=5)
+    ref = oracle_tvl1.tvl1_flow(gray.numpy(), oracle_tvl1.default_params(epsilon=0.0), nthreads=8)
+    out = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, stream_queue=1).cpu().numpy()
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 
 ROWS_SHAPES = [0, 4 * 16 + 4, 2 * 16 + 8, 3 * 16 + 5, 4 * 16 + 3, 8 * 16 + 2, 2 * 16 + 6]

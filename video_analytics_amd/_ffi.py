@@ -46,6 +46,7 @@ class Tvl1Params(ctypes.Structure):
         ("stream_slots", ctypes.c_int),
         ("rows_levels", ctypes.c_int),
         ("stream_ppl", ctypes.c_int),
+        ("stream_queue", ctypes.c_int),
         ("rows_cfg", ctypes.c_int),
     ]
 

@@ -334,6 +334,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef VA_REV
 #define VA_REV 1
 #endif
+#ifndef VA_STREAM_QUEUE_DEFAULT
+#define VA_STREAM_QUEUE_DEFAULT 0  // 1: k_iter_stream_q (all passes of a warp step in one launch) wherever it applies
+#endif
 #ifndef VA_STREAM_UNROLL2
 #define VA_STREAM_UNROLL2 1  // measured on the 224^2 level: 9.8 -> 9.3 ms per warp step of 320 pairs
 #endif
@@ -851,9 +854,8 @@ struct StreamArgs {
 // PPL pixels per lane: a strip is 64 * PPL columns wide (2: 128, the default; 3: 192, so that a 129..192-column level is
 // ONE well-filled strip without any x halo -- a tested option that measured no faster, see stream_ppl()).
 template <int PPL, int KH, int NWV, bool FAST>
-__global__ void __launch_bounds__(NWV * 64)
-    __attribute__((amdgpu_waves_per_eu((NWV == 1 && KH > 10) ? 1 : 2, (NWV == 1 && KH > 10) ? 1 : 2)))
-    k_iter_stream(StreamArgs a)
+__device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, const int job, const int K,
+                                           const float* __restrict__ sin_all, float* __restrict__ sout_all)
 {
     typedef Row<PPL> R;
     constexpr int NP = R::NP, NT = R::NT, SW = 64 * PPL;
@@ -866,15 +868,8 @@ __global__ void __launch_bounds__(NWV * 64)
     __shared__ f2 ifaceP[NWV > 1 ? NWV - 1 : 1][2][kNF_STATE][NP][64];
     __shared__ float ifaceT[NWV > 1 ? NWV - 1 : 1][2][kNF_STATE][NT ? 64 : 1];
 
-    unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
-    {
-        const unsigned nb = gridDim.x * gridDim.y, q = nb / 8, r = nb % 8, xcd = lid % 8, kk = lid / 8;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
-        if (a.rev) lid = nb - 1 - lid;
-    }
-    const int pair = a.pair0 + (int)(lid / gridDim.x), job = (int)(lid % gridDim.x);
     const int sx = job % a.nsx, ch = job / a.nsx;
-    const int w = a.w, h = a.h, pitch = a.pitch, K = a.K;
+    const int w = a.w, h = a.h, pitch = a.pitch;
     const int lane = threadIdx.x & 63;
     const int wv = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ox = sx * (SW - 2 * a.HX);
@@ -892,8 +887,8 @@ __global__ void __launch_bounds__(NWV * 64)
     const __amdgpu_buffer_rsrc_t rs_ro = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.ro + (size_t)pair * kNF_RO * a.plane), 0, kNF_RO * planeb, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.sin + (size_t)pair * kNF_STATE * a.plane), 0, kNF_STATE * planeb, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.sout + (size_t)pair * kNF_STATE * a.plane, 0,
+        const_cast<float*>(sin_all + (size_t)pair * kNF_STATE * a.plane), 0, kNF_STATE * planeb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(sout_all + (size_t)pair * kNF_STATE * a.plane, 0,
                                                                            kNF_STATE * planeb, 0x00020000);
     const int loff = colok ? x0 * (int)sizeof(float) : 0;
 
@@ -1152,6 +1147,96 @@ __global__ void __launch_bounds__(NWV * 64)
     } else {
         if (wv == 0) run(std::integral_constant<int, 0>{});
         else run(std::integral_constant<int, NWV - 1>{});
+    }
+}
+
+// One launch = one pass (a.K iterations) of every pair of the call: the grid is (strips x chunks, pairs).
+template <int PPL, int KH, int NWV, bool FAST>
+__global__ void __launch_bounds__(NWV * 64)
+    __attribute__((amdgpu_waves_per_eu((NWV == 1 && KH > 10) ? 1 : 2, (NWV == 1 && KH > 10) ? 1 : 2)))
+    k_iter_stream(StreamArgs a)
+{
+    unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const unsigned nb = gridDim.x * gridDim.y, q = nb / 8, r = nb % 8, xcd = lid % 8, kk = lid / 8;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+        if (a.rev) lid = nb - 1 - lid;
+    }
+    stream_job<PPL, KH, NWV, FAST>(a, a.pair0 + (int)(lid / gridDim.x), (int)(lid % gridDim.x), a.K, a.sin, a.sout);
+}
+
+// k_iter_stream_q: ALL passes of a warp step in one launch, as a queue of tasks (pass, pair, strip, chunk) that
+// persistent workgroups pull in that order.  A launch per pass is a barrier across ALL pairs of the call every 16
+// iterations (20-43 per warp step): its tail (workgroups of different length, the last partial round of workgroups on
+// the CUs) leaves SIMDs without waves -- the counters show the inner-iteration waves VALU-active 48 % of their lifetime,
+// two per SIMD, yet the chip only 64 % VALU-busy.  Here a pair's pass n + 1 may start as soon as THAT pair's pass n is
+// complete (a per-pair, per-pass completion counter), so pairs drift apart freely and the only tail is the one at the end
+// of the warp step.
+//   * task id = atomicAdd on a head word; ids are handed out pass-major, so every task a workgroup can be waiting for
+//     is held by a workgroup that is running: no deadlock whatever the residency; spins are bounded (abort flag);
+//   * hand-over between workgroups on different CUs (MI355X_MICROARCH.md, inter-workgroup visibility): producer =
+//     every storing wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, lane 0: agent-scope release fence,
+//     drain, agent-scope atomic add on the pair's counter; consumer = lane 0 polls the counter with relaxed agent-scope
+//     loads, ONE agent-scope acquire fence, drain, workgroup barrier, then plain loads;
+//   * same arithmetic, same job decomposition and the same buffers as the launch-per-pass form: bit-identical results.
+struct StreamQArgs {
+    StreamArgs base;      // geometry, constants, ro; K / sin / sout / rev unused
+    float* st[2];         // the two state buffers
+    unsigned* ctl;        // ctl[0] = next task id, ctl[1] = abort flag, ctl[2 + pair * npass + pass] = finished tasks
+    int cur;              // buffer holding the input of pass 0
+    int npass, K, Klast;  // passes of K iterations, the last one Klast
+    int npairs, tpp;      // pairs of the call, tasks (strips x chunks) per pair and pass
+};
+template <int PPL, int KH, int NWV, bool FAST>
+__global__ void __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_iter_stream_q(StreamQArgs q)
+{
+    // Control flow around the barriers is WAVE-uniform (scalar branches on the wave index; the one lane that adds to a
+    // counter is selected by the VALUE it adds, not by a branch): a per-lane `if (threadIdx.x == 0)` next to a barrier
+    // inside this loop is restructured by the compiler so that the other 63 lanes of the wave run ahead to the next
+    // barrier -- the wave then executes more barriers than its partner and the workgroup hangs (reproduced in isolation).
+    __shared__ int s_task;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned one_lane = lane == 0 ? 1u : 0u;
+    const int per_pass = q.npairs * q.tpp, total = per_pass * q.npass;
+    for (;;) {
+        if (wv == 0) {
+            int id = __builtin_amdgcn_readfirstlane((int)__hip_atomic_fetch_add(&q.ctl[0], one_lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (id < total && id >= per_pass) {
+                // wait for this pair's previous pass: all its tasks were handed out before this one
+                const int n = id / per_pass, pr = (id - n * per_pass) / q.tpp;
+                const unsigned* cnt = &q.ctl[2 + pr * q.npass + (n - 1)];
+                int spins = 0;
+                while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < q.tpp) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 22) ||
+                        __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&q.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) {
+                        __hip_atomic_store(&q.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // give up: never hang the GPU
+                        id = total;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            s_task = id;
+        }
+        __syncthreads();
+        const int id = __builtin_amdgcn_readfirstlane(s_task);  // uniform: the job's geometry stays in scalar registers
+        if (id >= total) return;
+        const int n = id / per_pass, rem = id - n * per_pass, pr = rem / q.tpp, job = rem - pr * q.tpp;
+        const int in = (q.cur ^ n) & 1;
+        float* const sin = in ? q.st[1] : q.st[0];
+        float* const sout = in ? q.st[0] : q.st[1];
+        stream_job<PPL, KH, NWV, FAST>(q.base, q.base.pair0 + pr, job, n == q.npass - 1 ? q.Klast : q.K, sin, sout);
+        // publish: every wave's stores have left, then one release + one counter add for the workgroup
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wv == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&q.ctl[2 + pr * q.npass + n], one_lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1729,7 +1814,8 @@ struct Plan {
     RowsPick rows[kMaxScales];
     size_t plane[kMaxScales];
     int NF, NP, F;
-    size_t off_pyr[kMaxScales], off_tmp, off_state[2], off_ro, off_err, off_sel, total;
+    size_t off_pyr[kMaxScales], off_tmp, off_state[2], off_ro, off_err, off_sel, off_ctl, total;
+    int ctl_words;  // k_iter_stream_q: head, abort flag and one completion counter per (pair, pass)
 };
 
 int zoom_taps(float step, Taps* t)
@@ -1762,6 +1848,7 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
     VA_CHECK_ARG(p->rows_levels >= -1 && p->rows_levels < (1 << kMaxScales) && p->rows_cfg >= 0 && p->rows_cfg < 256,
                  "va_tvl1: rows_levels must be -1 or a level bit set, rows_cfg in [0,255]");
     VA_CHECK_ARG(p->stream_ppl == 0 || p->stream_ppl == 2 || p->stream_ppl == 3, "va_tvl1: stream_ppl must be 0 (default), 2 or 3");
+    VA_CHECK_ARG(p->stream_queue >= 0 && p->stream_queue <= 2, "va_tvl1: stream_queue must be 0 (default), 1 (queued) or 2 (a launch per pass)");
     VA_CHECK_ARG(p->stream_levels >= -1 && p->stream_levels < (1 << kMaxScales) && (p->stream_waves == 0 || p->stream_waves == 1 || p->stream_waves == 3) &&
                      p->stream_chunks >= 0 && p->stream_slots >= 0,
                  "va_tvl1: stream_levels must be -1 or a level bit set, stream_waves 0 or 1, stream_chunks and stream_slots >= 0");
@@ -1815,6 +1902,9 @@ void make_plan(Plan& P, int w, int h, int n_seq, int fps, const va_tvl1_params* 
     if (p->epsilon > 0.0f) off += va_align_up((size_t)P.NP * p->iters * sizeof(unsigned long long), 256);
     P.off_sel = off;
     off += va_align_up((size_t)P.NP * 2 * sizeof(int), 256);
+    P.off_ctl = off;
+    P.ctl_words = 2 + P.NP * (p->iters / (2 * kStreamKH2) + 2);
+    off += va_align_up((size_t)P.ctl_words * sizeof(unsigned), 256);
     P.total = off;
 }
 
@@ -1854,6 +1944,7 @@ extern "C" void va_tvl1_default_params(va_tvl1_params* p)
     p->rows_levels = -1;
     p->rows_cfg = 0;
     p->stream_ppl = 0;
+    p->stream_queue = 0;
 }
 
 extern "C" int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* hs)
@@ -2078,7 +2169,33 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                 sa.theta = a.theta;
                 const dim3 grid(sp.nsx * sp.nch, nc);
                 const bool two = sp.two != 0;
-                for (int it = 0; it < p->iters;) {
+                // the queued form (all passes in one launch): two-wave pipeline, 2 pixels per lane, and a last pass deep
+                // enough to end in the second wave
+                const int qK = 2 * kStreamKH2, qn = va_cdiv(p->iters, qK), qlast = p->iters - (qn - 1) * qK;
+                const bool queued = two && sp.ppl == 2 && !sp.deep1 && qlast > kStreamKH2 &&
+                                    (p->stream_queue == 1 || (p->stream_queue == 0 && VA_STREAM_QUEUE_DEFAULT));
+                if (queued) {
+                    unsigned* ctl = (unsigned*)(ws + P.off_ctl);
+                    VA_HIP(hipMemsetAsync(ctl, 0, (size_t)P.ctl_words * sizeof(unsigned), st));
+                    StreamQArgs qa{};
+                    qa.base = sa;
+                    qa.st[0] = state[0];
+                    qa.st[1] = state[1];
+                    qa.ctl = ctl;
+                    qa.cur = cur;
+                    qa.npass = qn;
+                    qa.K = qK;
+                    qa.Klast = qlast;
+                    qa.npairs = nc;
+                    qa.tpp = sp.nsx * sp.nch;
+                    const int want = p->stream_slots > 0 ? p->stream_slots : 512;  // persistent workgroups: half the GPU's 1024 slots per call
+                    const int nwg = qa.npairs * qa.tpp < want ? qa.npairs * qa.tpp : want;
+                    if (p->fast_math) k_iter_stream_q<2, kStreamKH2, 2, true><<<nwg, 128, 0, st>>>(qa);
+                    else k_iter_stream_q<2, kStreamKH2, 2, false><<<nwg, 128, 0, st>>>(qa);
+                    cur ^= qn & 1;
+                    launches = 1;
+                }
+                for (int it = queued ? p->iters : 0; it < p->iters;) {
                     const int rem = p->iters - it;
                     const int kh2 = stream_kh2(sp.ppl), k1 = stream_k1(sp.ppl);
                     const bool w2 = two && rem > kh2 && !sp.deep1;  // the two-wave kernel needs its last level in the second wave
