@@ -92,10 +92,14 @@ size_t va_vgg16_workspace_bytes(const va_vgg16* model, int batch);
  * A/B and test switches of ONE model handle (defaults are the measured choices of DESIGN.md; results of the
  * fp32 path do not depend on VA_OPT_F32_CONV_KERNEL, the three bf16 variants are bit-identical to each other):
  *   VA_OPT_BF16_VARIANT     0 (default) tile and staging scheme chosen per layer; 1 = 64-channel tiles with one
- *                           LDS buffer on every layer; 2 = the LDS-DMA ring on every layer; 3 / 4 = the halo-brick
+ *                           LDS buffer on every layer; 2 = the LDS-DMA ring on every layer; 5 = the two-group kernel (k_conv3x3_pp_bf16)
+ *                           on the layers with >= 128 output channels and >= 28x28 pixels; 3 / 4 = the halo-brick
  *                           kernel on the layers of 28x28 pixels and more (8 waves with 64-pixel wave tiles / 4 waves
  *                           with 128-pixel wave tiles; chunk-major K order: another fp32 summation order, so within
  *                           bf16 noise of 0..2 rather than bit-identical; measured no faster)
+ *   VA_OPT_BF16_FIRST_LAYER 1 (default) the first layer reads the NCHW input itself (k_conv1_fused_bf16); 0 = the input is
+ *                           first staged as a 64-channel NHWC tensor and convolved in three K steps (the round-1 path;
+ *                           another fp32 summation order: bf16-level agreement).  Independent of VA_OPT_BF16_VARIANT
  *   VA_OPT_F32_CONV_KERNEL  1 (default) LDS-DMA staged fp32 kernel where Cin % 32 == 0; 0 = register-staged kernel
  *   VA_OPT_TRAIN_STOP_AT    -1 (default) full training step; i in [0,12]: va_vgg16_train_step returns
  *                           VA_ERR_STOPPED after the backward pass of conv layer i, leaving the gradient buffers
@@ -104,6 +108,7 @@ size_t va_vgg16_workspace_bytes(const va_vgg16* model, int batch);
 #define VA_OPT_BF16_VARIANT 1
 #define VA_OPT_F32_CONV_KERNEL 2
 #define VA_OPT_TRAIN_STOP_AT 3
+#define VA_OPT_BF16_FIRST_LAYER 4
 int va_vgg16_set_option(va_vgg16* model, int option, int value);
 
 /*

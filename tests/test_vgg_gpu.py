@@ -97,6 +97,23 @@ def test_u8_input_normalisation_matches_oracle(weights3):
     m.close()
 
 
+def test_bf16_u8_input_goes_through_the_fused_first_layer(weights3):
+    # the bf16 first layer converts u8 frames itself (ToTensor + Normalize in the kernel): same scores as the bf16 model fed
+    # the normalised floats, up to bf16 roundings of inputs that differ in their last float bit
+    from oracle import vgg_oracle
+    from video_analytics_amd import synth, vgg
+    from video_analytics_amd.parameters import NORM_MEANS_TF, NORM_STDS_TF
+    w = weights3
+    rgb, _, _ = synth.synth_clips(3, seed=5)
+    xr = vgg_oracle.normalize_u8(rgb, NORM_MEANS_TF, NORM_STDS_TF)
+    m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256, NORM_MEANS_TF, NORM_STDS_TF, dtype="bf16")
+    _, _, log_u8 = m.forward(rgb.cuda())
+    _, _, log_f = m.forward(xr.cuda())
+    ls = float(log_f.abs().max())
+    assert float((log_u8 - log_f).abs().max()) / ls < 1e-2
+    m.close()
+
+
 def test_batch_40_crosses_fc_row_tile(weights3):
     # 40 > 32: two FC row tiles and a partial conv batch brick; compare rows 0..2 and 37..39 with the oracle
     from oracle import vgg_oracle
@@ -196,7 +213,7 @@ def test_bf16_stream_against_its_own_restatement_and_across_staging_schemes(weig
     feat_r, desc_r, log_r = vgg_oracle.forward_bf16(x, w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"])
     outs = []
     from video_analytics_amd import _ffi
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 5):  # (5: the two-group kernel -- the same K order per accumulator, so bit-equal too)
         m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256, dtype="bf16")
         m.set_option(_ffi.VA_OPT_BF16_VARIANT, variant)
         feat, desc, logits = m.forward(x.cuda(), want_feat=True)
@@ -226,6 +243,17 @@ def test_bf16_stream_against_its_own_restatement_and_across_staging_schemes(weig
         brick.append((feat.cpu(), logits.cpu()))
         m.close()
     assert torch.equal(brick[0][0], brick[1][0]) and torch.equal(brick[0][1], brick[1][1])  # same K order in both wave tilings
+    # the first layer: by default it reads the NCHW input itself (k_conv1_fused_bf16); VA_OPT_BF16_FIRST_LAYER = 0 is the
+    # staged path (input conversion + three K steps) -- for 3 channels another grouping of the sum, the same bf16 noise level
+    m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256, dtype="bf16")
+    m.set_option(_ffi.VA_OPT_BF16_FIRST_LAYER, 0)
+    feat, desc, logits = m.forward(x.cuda(), want_feat=True)
+    ef, el = float((feat.cpu() - feat_r).abs().max()), float((logits.cpu() - log_r).abs().max())
+    assert ef / fs < 1e-2 and el / ls < 1e-2, ("staged first layer", ef, fs, el, ls)
+    assert float((logits.cpu() - outs[0][1]).abs().max()) / ls < 1e-2
+    if c_in % 4 == 0:  # (no channel padding in the patch: the same products in the same order, so even bit-equal)
+        assert torch.equal(feat.cpu(), outs[0][0])
+    m.close()
 
 
 def test_validate_batch_matches_oracle():

@@ -3,7 +3,9 @@ Run on the GPU box: python tools/bench_cnn_only.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from video_analytics_amd import pipeline, synth
+from video_analytics_amd import pipeline, synth, _ffi as _f
+if os.environ.get("VA_LIB_EXP"):
+    _f.LIB_PATH = os.path.abspath(os.environ["VA_LIB_EXP"])  # timing experiments with another build
 dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
 pipe = pipeline.TwoStreamPipeline(device=0, cnn_dtype=dtype)
 if len(sys.argv) > 2:  # python tools/bench_cnn_only.py bf16 <VA_OPT_BF16_VARIANT>

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libva_hip.so")
 
 VA_OK, VA_ERR_INVALID, VA_ERR_HIP, VA_ERR_WORKSPACE, VA_ERR_STOPPED = 0, 1, 2, 3, 4
-VA_OPT_BF16_VARIANT, VA_OPT_F32_CONV_KERNEL, VA_OPT_TRAIN_STOP_AT = 1, 2, 3
+VA_OPT_BF16_VARIANT, VA_OPT_F32_CONV_KERNEL, VA_OPT_TRAIN_STOP_AT, VA_OPT_BF16_FIRST_LAYER = 1, 2, 3, 4
 
 # every symbol include/va.h declares (tests check that the library exports exactly these)
 EXPORTS = [

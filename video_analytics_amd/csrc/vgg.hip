@@ -436,7 +436,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // s_waitcnt vmcnt, raw s_barrier, one barrier per step) for the layers that cannot put several workgroups on
 // every CU (14x14: 392 workgroups of 72 latency-bound steps).
 template <int NT, bool POOL, bool OUT_F32, int NBUF>
-__global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) k_conv3x3_mfma_bf16(ConvArgsBf a)
+__device__ __forceinline__ void conv3x3_mfma_bf16_body(const ConvArgsBf& a)
 {
     constexpr int BM = 128, BN = NT * 64, MT = 2;
     constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;  // LDS-DMA instructions per wave and K step (8 rows each)
@@ -456,28 +456,42 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) k_conv3x3_mfma_bf16(Co
     const int H = a.H, W = a.W, Cin = a.Cin;
     const int X0 = tile_x << a.lgTW, Y0 = tile_y << a.lgTH, B0 = tile_b * a.TB;
 
-    // loader role: row (lane >> 3) of the 8-row group, slot (lane & 7)
+    // loader role: row (lane >> 3) of the 8-row group, slot (lane & 7).
+    // Addressing: buffer loads to LDS.  The activation resource starts (W + 1) pixels BEFORE the tensor, so that the tap
+    // offset ((ky + 1) W + kx + 1) Cin + c0 is a non-negative scalar (soffset) and a lane's own offset carries the same
+    // bias; a lane whose tap falls outside the image gets an out-of-range offset, for which the buffer load writes zeros
+    // (no zero line, no 64-bit pointer select per piece and step); a lane's nine in-image decisions are nine bits.
     const int lrow = lane >> 3, lslot = lane & 7;
-    int ax[A_INSTR], ay[A_INSTR];
-    long apix[A_INSTR];
-    bool aok[A_INSTR];
+    const long bias_el = (long)(W + 1) * Cin;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(a.in) - bias_el, 0, (int)(((long)a.B * H * W * Cin + 2 * bias_el) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(a.wp), 0, (int)((long)a.Cout * 3 * a.taps_x * Cin * 2), 0x00020000);
+    int aoff[A_INSTR];
+    unsigned amask[A_INSTR];
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
         const int row = (wave * A_INSTR + i) * 8 + lrow;
         const int c = lslot ^ ((row >> 1) & 7);
         int xl, yl, bl;
         brick_coords(row, a.lgTW, a.lgTH, xl, yl, bl);
-        ax[i] = X0 + xl;
-        ay[i] = Y0 + yl;
-        const int b = B0 + bl;
-        aok[i] = b < a.B && ax[i] < W && ay[i] < H;
-        apix[i] = (((long)b * H + ay[i]) * W + ax[i]) * Cin + 8 * c;
+        const int x = X0 + xl, y = Y0 + yl, b = B0 + bl;
+        const bool ok = b < a.B && x < W && y < H;
+        aoff[i] = (int)(((((long)b * H + y) * W + x) * Cin + 8 * c) * 2);
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int ky = a.taps_x == 3 ? k / 3 - 1 : k - 1, kx = a.taps_x == 3 ? k % 3 - 1 : 0;
+            const int yy = y + ky, xx = x + kx;
+            m |= (ok && k < 3 * a.taps_x && yy >= 0 && yy < H && xx >= 0 && xx < W) ? 1u << k : 0u;
+        }
+        amask[i] = m;
     }
-    const __bf16* wrow[B_INSTR];
+    int boff[B_INSTR];
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
         const int row = (wave * B_INSTR + i) * 8 + lrow;
-        wrow[i] = a.wp + (size_t)(n0 + row) * 3 * a.taps_x * Cin + 8 * (lslot ^ ((row >> 1) & 7));
+        boff[i] = (int)(((long)(n0 + row) * 3 * a.taps_x * Cin + 8 * (lslot ^ ((row >> 1) & 7))) * 2);
     }
 
     f32x16 acc[MT][NT];
@@ -492,29 +506,35 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) k_conv3x3_mfma_bf16(Co
     const int T = 3 * a.taps_x * cchunks;
     const int r31 = lane & 31, hh = lane >> 5;
     const int fsw = (r31 >> 1) & 7;  // fragment rows are (multiple of 32) + r31
-    int kp = 0, c0 = 0;
+    int kp = 0, kx = 0, c0 = 0;
+    // scalar byte offsets of the step: ((ky + 1) W + kx + 1) Cin + c0 (activations, biased), kp Cin + c0 (weights)
+    int so_a = a.taps_x == 3 ? 0 : Cin * 2, so_b = 0;
     // LDS-DMA of K step (kp, c0) into ring slot `buf`; advances (kp, c0)
     auto stage = [&](int buf) {
         __bf16* const sA = smem + buf * TILE;
         __bf16* const sB = sA + BM * kBfBK;
-        const int ky = a.taps_x == 3 ? kp / 3 - 1 : kp - 1, kx = a.taps_x == 3 ? kp % 3 - 1 : 0;
-        const long tap = ((long)ky * W + kx) * Cin + c0;
         static_for<A_INSTR>([&](auto I) {
             constexpr int i = decltype(I)::value;
-            const int yy = ay[i] + ky, xx = ax[i] + kx;
-            const bool ok = aok[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const __bf16* src = ok ? a.in + apix[i] + tap : a.zeros;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sA + (wave * A_INSTR + i) * 8 * kBfBK), 16, 0, 0);
+            const int vo = (amask[i] >> kp) & 1 ? aoff[i] : 0x7fffffff;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(sA + (wave * A_INSTR + i) * 8 * kBfBK), 16, vo, so_a, 0, 0);
         });
         static_for<B_INSTR>([&](auto I) {
             constexpr int i = decltype(I)::value;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wrow[i] + (size_t)kp * Cin + c0),
-                                             (lds_ptr_t)(sB + (wave * B_INSTR + i) * 8 * kBfBK), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(sB + (wave * B_INSTR + i) * 8 * kBfBK), 16, boff[i], so_b, 0, 0);
         });
         c0 += kBfBK;
-        if (c0 == Cin) {
+        so_a += kBfBK * 2;
+        so_b += kBfBK * 2;
+        if (c0 == Cin) {  // next tap: one pixel to the right, or (3 x 3 taps: two pixels short of) a row down
             c0 = 0;
             ++kp;
+            if (a.taps_x == 3) {
+                ++kx;
+                so_a += kx == 3 ? (W - 3) * Cin * 2 : 0;
+                kx = kx == 3 ? 0 : kx;
+            } else {
+                so_a += (W - 1) * Cin * 2;
+            }
         }
     };
     auto compute = [&](int buf) {
@@ -607,6 +627,162 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) k_conv3x3_mfma_bf16(Co
                 }
             }
         }
+    }
+}
+
+// (the body is a __device__ function: buffer-resource builtins in a __global__ template body keep the host pass from
+// emitting the kernel's stub)
+template <int NT, bool POOL, bool OUT_F32, int NBUF>
+__global__ void __launch_bounds__(256, NBUF == 1 ? 4 : 2) k_conv3x3_mfma_bf16(ConvArgsBf a)
+{
+    conv3x3_mfma_bf16_body<NT, POOL, OUT_F32, NBUF>(a);
+}
+
+// ---------------------------------------------------------------- bf16 first layer, fused with the input conversion ----
+//
+// The first layer has 3 (RGB) or 20 (flow stack) input channels: its K is 27 / 180, its cost is the 205 MB of bf16
+// activations it writes per 32 images.  Staging its input as a 64-channel NHWC tensor first (k_nchw_to_nhwc_xcol) writes
+// and re-reads another 205 MB.  k_conv1_fused_bf16 reads the NCHW input directly: a workgroup owns a 16 x 16 pixel brick
+// of one image and all 64 output channels,
+//   * converts the brick's 18 x 18 halo patch (u8: ToTensor + Normalize, the expression of k_nchw_to_nhwc_pad; zeros
+//     outside the image) to bf16 in LDS, pixel-major with Cp = C rounded up to 4 channels per pixel: the 3 Cp values of
+//     the pixels x-1, x, x+1 of one patch row are then CONTIGUOUS -- they are row ky of the pixel's im2col line
+//     (element kx Cp + c), and an MFMA fragment is 8 consecutive elements of that run (two ds_read_b64; a run is rounded
+//     up to KROW = 16-element blocks whose tail reads the next pixels' finite values against zero weights);
+//   * holds the packed weights [64][3][KROW] in LDS (k_pack_conv_w_bf16_f1);
+//   * multiplies with the WEIGHTS as the MFMA's first operand: a lane then owns four consecutive output channels of one
+//     pixel per accumulator quad, packs them to 8 bytes, and the wave transposes its 64 pixels x 64 channels through LDS
+//     so that every pixel's 128-byte line goes to memory whole (16 bytes per lane, 8 full lines per store instruction).
+// K = 3 KROW: 48 for RGB (3 MFMA k-blocks per accumulator), 192 for the flow stack (12).
+struct Conv1Args {
+    const void* x;       // NCHW [B][C][224][224], f32 or u8
+    const __bf16* wp;    // [64][3][KROW]
+    const float* bias;   // [64]
+    __bf16* out;         // NHWC [B][224][224][64]
+    const float* mean;   // u8 input: ToTensor + Normalize
+    const float* stdv;
+    int B, C, Cp, KROW;
+};
+
+constexpr int kF1MaxCp = 24, kF1MaxKrow = 80;
+
+__global__ void k_pack_conv_w_bf16_f1(const float* __restrict__ w, __bf16* __restrict__ wp, int Cout, int Cin, int Cp, int KROW)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cout * 3 * KROW) return;
+    const int j = idx % KROW, ky = (idx / KROW) % 3, n = idx / (3 * KROW);
+    const int kx = j / Cp, ci = j - kx * Cp;
+    wp[idx] = (__bf16)((kx < 3 && ci < Cin) ? w[((size_t)n * Cin + ci) * 9 + ky * 3 + kx] : 0.0f);
+}
+
+template <typename TIN>
+__global__ void __launch_bounds__(256) k_conv1_fused_bf16(Conv1Args a)
+{
+    constexpr int H = 224, W = 224, TW = 16, PW = 18, NPIX = 18 * 18, NPAD = NPIX + 12;
+    constexpr int PATCH_EL = NPAD * kF1MaxCp;             // bf16 elements
+    constexpr int WS_MAX = 3 * kF1MaxKrow + 8;            // weight row stride (elements): + 16 B against bank conflicts
+    constexpr int OST = 64 + 8;                           // staging row stride (elements): 144 B
+    constexpr int SMEM_A = (PATCH_EL + 64 * WS_MAX) * 2, SMEM_B = 4 * 64 * OST * 2;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_A > SMEM_B ? SMEM_A : SMEM_B];
+    __bf16* const patch = (__bf16*)smem;
+    __bf16* const wl = patch + PATCH_EL;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.C, Cp = a.Cp, KROW = a.KROW, WS = 3 * KROW + 8, NBK = KROW / 16;
+    int bid = blockIdx.x;
+    const int tx = bid % (W / TW);
+    bid /= (W / TW);
+    const int ty = bid % (H / TW);
+    const int b = bid / (H / TW);
+    const int X0 = tx * TW, Y0 = ty * TW;
+
+    // zero the patch (pad channels, pad pixels), then fill it; copy the weights
+    for (int i = tid; i < NPAD * Cp / 8; i += 256) ((uint4*)patch)[i] = uint4{0, 0, 0, 0};
+    for (int i = tid; i < 64 * 3 * KROW / 8; i += 256) {
+        const int n = i / (3 * KROW / 8), r = i - n * (3 * KROW / 8);
+        *(uint4*)(wl + n * WS + 8 * r) = ((const uint4*)a.wp)[i];
+    }
+    __syncthreads();
+    const TIN* const xin = (const TIN*)a.x + (size_t)b * C * H * W;
+    for (int i = tid; i < NPIX * C; i += 256) {
+        const int c = i / NPIX, p = i - c * NPIX;
+        const int py = p / PW, px = p - py * PW;
+        const int gy = Y0 - 1 + py, gx = X0 - 1 + px;
+        float v = 0.0f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const TIN raw = xin[((size_t)c * H + gy) * W + gx];
+            if constexpr (sizeof(TIN) == 1) v = ((float)raw / 255.0f - a.mean[c]) / a.stdv[c];
+            else v = (float)raw;
+        }
+        patch[p * Cp + c] = (__bf16)v;
+    }
+    __syncthreads();
+
+    const int r31 = lane & 31, hh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    // this lane's pixels: m = 64 wave + 32 mt + r31, row-major in the 16 x 16 brick
+    int pbase[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = 64 * wave + 32 * mt + r31;
+        pbase[mt] = ((m >> 4) * PW + (m & 15)) * Cp;  // patch pixel (y - 1, x - 1): tap (ky, kx) = (0, 0) of pixel m
+    }
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kb = 0; kb < NBK; ++kb) {
+            const int j0 = kb * 16 + hh * 8;
+            bf16x8 fx[2], fw[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const s4* p = (const s4*)(patch + pbase[mt] + ky * PW * Cp + j0);
+                const s4 lo = p[0], hi = p[1];
+                const s8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                fx[mt] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) fw[nt] = *(const bf16x8*)(wl + (32 * nt + r31) * WS + ky * KROW + j0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nt], fx[mt], acc[mt][nt], 0, 0, 0);
+        }
+    __syncthreads();  // every wave is done with the patch and the weights: the staging tiles take their place
+
+    // accumulator (mt, nt), register 4 g4 + j: channel 32 nt + 8 g4 + 4 hh + j of pixel 32 mt + r31 of this wave
+    __bf16* const ost = (__bf16*)smem + wave * 64 * OST;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int n = 32 * nt + 8 * g4 + 4 * hh;
+            const float4 bs = *(const float4*)(a.bias + n);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                bf16x4 v;
+                v.x = (__bf16)fmaxf(acc[mt][nt][4 * g4 + 0] + bs.x, 0.0f);
+                v.y = (__bf16)fmaxf(acc[mt][nt][4 * g4 + 1] + bs.y, 0.0f);
+                v.z = (__bf16)fmaxf(acc[mt][nt][4 * g4 + 2] + bs.z, 0.0f);
+                v.w = (__bf16)fmaxf(acc[mt][nt][4 * g4 + 3] + bs.w, 0.0f);
+                *(bf16x4*)(ost + (32 * mt + r31) * OST + n) = v;
+            }
+        }
+    // (the tile is private to the wave: its own LDS writes are ordered before its reads)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int ch = it * 64 + lane, pl = ch >> 3, c8 = ch & 7;
+        const uint4 v = *(const uint4*)(ost + pl * OST + 8 * c8);
+        const int m = 64 * wave + pl, y = Y0 + (m >> 4), x = X0 + (m & 15);
+        *(uint4*)(a.out + (((size_t)b * H + y) * W + x) * 64 + 8 * c8) = v;
     }
 }
 
@@ -809,6 +985,218 @@ __global__ void __launch_bounds__(2048 / MT) k_conv3x3_brick_bf16(ConvArgsBf a)
             }
         }
     }
+}
+
+// ---------------------------------------------------------------- bf16 conv3x3, two wave groups in turns ------
+//
+// k_conv3x3_pp_bf16: 512 threads = two GROUPS of four waves (one wave of each group on every SIMD).  The workgroup tile is
+// 256 pixels x (NT * 64) channels; group g owns the pixels [128 g, 128 g + 128), its four waves (2 x 2) a 64 x (NT * 32)
+// tile each.  The K loop runs in steps of 32 channels of one tap, and every step of a group has two phases:
+//   L(t): issue this wave's share of the LDS-DMA of step t + 3, then read ALL the step's fragments from LDS into registers;
+//   C(t): the step's 4 * NT MFMAs, operands in registers, no memory instruction.
+// The groups run half a step apart -- while group 0 is in C(t), group 1 is in L(t), and the other way round -- and one
+// workgroup barrier separates the phases: the matrix pipe of a SIMD always has one wave in C while its partner does the
+// address arithmetic, the DMA issue and the LDS reads (MI355X_MICROARCH.md, "Two waves per SIMD").  A ring of four
+// 32-channel tiles (16 KB of pixels + NT * 4 KB of weights each) keeps three steps of DMA in flight; waits are counted
+// (s_waitcnt vmcnt) so that nothing is drained that is not needed in the next phase.
+//   * LDS rows are 64 B (32 channels); the bank swizzle sits on the source side as in the kernels above: lane (row r,
+//     slot p) of a DMA piece (16 rows x 64 B) fetches chunk p ^ ((r >> 2) & 3); a fragment read of chunk c of row m goes
+//     to slot c ^ ((m >> 2) & 3): the 16 lanes of a ds_read_b128 group then cover a 256-byte bank row exactly once.
+//   * K order: tap-major, 32-channel chunks inside a tap -- the same fp32 summation order as k_conv3x3_mfma_bf16 up to
+//     the split of each 64-channel step into two (sums of the same products; bf16-level agreement, tested).
+template <int NT, bool POOL>
+__device__ __forceinline__ void conv3x3_pp_body(const ConvArgsBf& a)
+{
+    constexpr int BM = 256, BN = NT * 64, MT = 2, KB = 32, NB = 4, D = 3;
+    constexpr int ROWB = KB * 2;                              // bytes of an LDS row
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int APW = 2;                                    // A pieces (16 rows) per wave and step: 128 rows / 4 waves
+    constexpr int BPW = (BN / 16 + 7) / 8;                    // B pieces per wave and step
+    constexpr int PW = APW + BPW;
+    static_assert(BN % 128 == 0, "every wave stages whole pieces of the weight tile");
+    __shared__ __attribute__((aligned(1024))) char smem[NB * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, q = wave & 3, wm = q >> 1, wn = q & 1;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_tile = bid % a.tiles_n;
+    bid /= a.tiles_n;
+    const int tile_x = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int tile_y = bid % a.tiles_y;
+    const int tile_b = bid / a.tiles_y;
+    const int n0 = n_tile * BN;
+    const int H = a.H, W = a.W, Cin = a.Cin;
+    const int X0 = tile_x << a.lgTW, Y0 = tile_y << a.lgTH, B0 = tile_b * a.TB;
+
+    // loader role: row (lane >> 2) of a 16-row piece, slot (lane & 3); the chunk this lane fetches.
+    // Addressing: buffer loads to LDS.  The activation resource starts (W + 1) pixels BEFORE the tensor, so that the tap
+    // offset ((ky + 1) W + kx + 1) Cin + c0 is a non-negative scalar (soffset); a lane's own offset carries the same
+    // bias.  A lane whose tap falls outside the image gets an out-of-range offset: the buffer load then writes zeros --
+    // no zero line, no pointer select; the nine in-image decisions of a lane are nine bits computed once.
+    const int lrow = lane >> 2, lchunk = (lane & 3) ^ ((lrow >> 2) & 3);
+    const long bias_el = (long)(W + 1) * Cin;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(a.in) - bias_el, 0, (int)(((long)a.B * H * W * Cin + 2 * bias_el) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wp), 0, (int)((long)a.Cout * 9 * Cin * 2), 0x00020000);
+    int aoff[APW];
+    unsigned amask[APW];
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const int row = 128 * g + 32 * q + 16 * i + lrow;
+        int xl, yl, bl;
+        brick_coords(row, a.lgTW, a.lgTH, xl, yl, bl);
+        const int x = X0 + xl, y = Y0 + yl, b = B0 + bl;
+        const bool ok = b < a.B && x < W && y < H;
+        aoff[i] = (int)(((((long)b * H + y) * W + x) * Cin + 8 * lchunk) * 2);
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+            m |= (ok && yy >= 0 && yy < H && xx >= 0 && xx < W) ? 1u << k : 0u;
+        }
+        amask[i] = m;
+    }
+    int boff[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) boff[i] = (int)(((long)(n0 + (wave * BPW + i) * 16 + lrow) * 9 * Cin + 8 * lchunk) * 2);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    const int T = 9 * (Cin / KB);
+    const int r31 = lane & 31, hh = lane >> 5, fsw = (r31 >> 2) & 3;
+    // the next step to stage: tap kp = 3 ky + kx, channel offset c0, the two scalar byte offsets, ring slot
+    int kp = 0, kx = 0, c0 = 0, sbuf = 0;
+    int so_a = 0, so_b = 0;  // ((ky W + kx) Cin + c0) * 2 (biased: tap (-1,-1) is 0);  (kp Cin + c0) * 2
+    auto stage = [&]() {
+        char* const sA = smem + sbuf * STAGE;
+        char* const sB = sA + A_BYTES;
+        static_for<APW>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const int vo = (amask[i] >> kp) & 1 ? aoff[i] : 0x7fffffff;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(sA + (128 * g + 32 * q + 16 * i) * ROWB), 16, vo, so_a, 0, 0);
+        });
+        static_for<BPW>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(sB + (wave * BPW + i) * 16 * ROWB), 16, boff[i], so_b, 0, 0);
+        });
+        c0 += KB;
+        so_a += KB * 2;
+        so_b += KB * 2;
+        if (c0 == Cin) {  // next tap: one pixel to the right, or two pixels short of a row down
+            c0 = 0;
+            ++kp;
+            ++kx;
+            so_a += kx == 3 ? (W - 3) * Cin * 2 : 0;
+            kx = kx == 3 ? 0 : kx;
+        }
+        sbuf = sbuf + 1 == NB ? 0 : sbuf + 1;
+    };
+    // wait until at most `steps` staged steps of this wave are still in flight, and its LDS reads are done; then the barrier
+    auto sync = [&](int steps) {
+        if (steps >= 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (steps == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PW) : "memory");
+        else if (steps == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    for (int j = 0; j < D; ++j) stage();  // (T >= 18 > D)
+    sync(D - 1);                          // step 0 has landed
+    if (g == 1) sync(3);                  // group 1 starts half a step later
+
+    bf16x8 fa[MT][KB / 16] = {}, fb[NT][KB / 16] = {};
+    int rbuf = 0;
+    // one step of this wave's group: L(t) (the step's fragments into registers, then the DMA of step t + D), barrier, C(t),
+    // barrier.  MAIN: step t + D exists (the straight-line body of all but the last D steps)
+    auto step = [&](const int t, auto main_tag) __attribute__((always_inline)) {
+        constexpr bool MAIN = decltype(main_tag)::value;
+        {
+            const char* const sA = smem + rbuf * STAGE;
+            const char* const sB = sA + A_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < KB / 16; ++ks) {
+                const int slot = ((2 * ks + hh) ^ fsw) * 16;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    fa[mt][ks] = *reinterpret_cast<const bf16x8*>(sA + (128 * g + (wm * MT + mt) * 32 + r31) * ROWB + slot);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    fb[nt][ks] = *reinterpret_cast<const bf16x8*>(sB + ((wn * NT + nt) * 32 + r31) * ROWB + slot);
+            }
+            rbuf = rbuf + 1 == NB ? 0 : rbuf + 1;
+        }
+        if (MAIN || t + D < T) stage();
+        // steps still in flight that the NEXT reader of the ring does not need: t + 2 .. min(t + D, T - 1).  Group 0's
+        // L(t + 1) is two phases away (nothing to wait for yet); group 1's L(t) is followed at once by group 0's L(t + 1)
+        const int inflight = MAIN ? D - 1 : (t + D < T ? t + D : T - 1) - (t + 1);
+        if (g == 0) sync(3);
+        else sync(inflight);
+#pragma unroll
+        for (int ks = 0; ks < KB / 16; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][ks], fb[nt][ks], acc[mt][nt], 0, 0, 0);
+        if (g == 0) sync(inflight);       // before group 0's own L(t + 1) (and group 1's C(t))
+        else if (MAIN || t + 1 < T) sync(3);  // group 1 has no partner phase after its last C
+    };
+    int t = 0;
+    for (; t < T - D; ++t) step(t, std::true_type{});
+    for (; t < T; ++t) step(t, std::false_type{});
+
+    // epilogue: bias + ReLU (+ 2x2 max-pool over the 4 registers reg&3 of a lane), fp32 math, bf16 store
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + (wn * NT + nt) * 32 + r31;
+        const float bias = a.bias[n];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int mbase = 128 * g + (wm * MT + mt) * 32 + 8 * g4 + 4 * hh;
+                int xl, yl, bl;
+                brick_coords(mbase, a.lgTW, a.lgTH, xl, yl, bl);
+                const int x = X0 + xl, y = Y0 + yl, b = B0 + bl;
+                if (b >= a.B) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[mt][nt][4 * g4 + j] + bias, 0.0f);
+                if constexpr (POOL) {
+                    if (x < W && y < H) {
+                        const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        const size_t o = ((((size_t)b * (H >> 1)) + (y >> 1)) * (W >> 1) + (x >> 1)) * a.Cout + n;
+                        ((__bf16*)a.out)[o] = (__bf16)mx;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int xx = x + (j & 1), yy = y + (j >> 1);
+                        if (xx < W && yy < H) {
+                            const size_t o = (((size_t)b * H + yy) * W + xx) * a.Cout + n;
+                            ((__bf16*)a.out)[o] = (__bf16)v[j];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// (the body is a __device__ function: buffer-resource builtins in a __global__ template body keep the host pass from
+// emitting the kernel's stub)
+template <int NT, bool POOL>
+__global__ void __launch_bounds__(512) k_conv3x3_pp_bf16(ConvArgsBf a)
+{
+    conv3x3_pp_body<NT, POOL>(a);
 }
 
 // ---------------------------------------------------------------- fp32 conv3x3, LDS-DMA staging ---------
@@ -1140,22 +1528,26 @@ constexpr long VA_WIDE_MIN = 512;           // register-staged fp32 kernel: 128-
 constexpr int VA_RING = 3;                  // depth of the LDS-DMA ring (two workgroups per CU)
 constexpr long VA_RING_MAXGRID = 1024;      // bf16: ring + 64-channel tiles below this many workgroups (the 14x14 layers)
 constexpr long VA_RING_MAXGRID_F32 = 1024;  // fp32: the same threshold (0 and 4096 measured 2-4 % slower)
+#ifndef VA_PP_DEFAULT
+#define VA_PP_DEFAULT 1     // bf16: the two-group kernel where launch_conv_bf16 measured it faster (0: never by default)
+#endif
 #ifndef VA_BRICK_DEFAULT
 #define VA_BRICK_DEFAULT 0  // bf16: 1 = the halo-brick kernel wherever it applies (set after measurement)
 #endif
 constexpr int VA_F32_CONV_DEFAULT = 1;      // 1: LDS-DMA fp32 kernel where Cin % 32 == 0; va_vgg16_set_option(VA_OPT_F32_CONV_KERNEL, 0) selects the register-staged one (A/B)
 constexpr int VA_CIN_ALIGN = 16;            // fp32 first-layer channel padding (3 -> 16: register-staged kernel; 20 -> 32: DMA kernel)
 
-void pick_brick(int W, int H, int B, int& lgTW, int& lgTH, int& TB)
+void pick_brick(int W, int H, int B, int& lgTW, int& lgTH, int& TB, int lgpx = 7)
 {
-    // 128 pixels = TW x TH x TB, powers of two, TW,TH >= 2: maximise the fraction of real pixels.
+    // 128 (2^lgpx) pixels = TW x TH x TB, powers of two, TW,TH >= 2: maximise the fraction of real pixels.
     double best = -1.0;
     for (int lw = 1; lw <= 5; ++lw)
-        for (int lh = 1; lw + lh <= 7; ++lh) {
-            const int tw = 1 << lw, th = 1 << lh, tb = 128 / (tw * th);
+        for (int lh = 1; lw + lh <= lgpx; ++lh) {
+            const int tw = 1 << lw, th = 1 << lh, tb = (1 << lgpx) / (tw * th);
             const double cover = (double)va_cdiv(W, tw) * tw * va_cdiv(H, th) * th * (double)va_cdiv(B, tb) * tb;
             double util = (double)W * H * B / cover;
             util += 1e-3 * lw;  // tie-break: wider bricks (longer contiguous runs in x)
+            if (lgpx != 7) util += 5e-4 * lh;  // (256-pixel bricks: then taller ones -- the taps of a brick overlap in cache)
             if (util > best) {
                 best = util;
                 lgTW = lw;
@@ -1285,6 +1677,36 @@ int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const
         pick_brick(L.hw, L.hw, B, a.lgTW, a.lgTH, a.TB);
         a.tiles_x = va_cdiv(L.hw, 1 << a.lgTW);
         a.tiles_y = va_cdiv(L.hw, 1 << a.lgTH);
+    }
+    // The two-group kernel (k_conv3x3_pp_bf16).  variant 5: on every layer with >= 128 output channels and at least
+    // 28 x 28 pixels.  Default: where it measured faster (B = 32, profiles/README.md): the 256-channel tiles whose grid of
+    // 256-pixel x 256-channel workgroups is ONE round of the 256 CUs (the 28 x 28 layers: 196 workgroups, 105 / 107 us
+    // against 117 / 139 us), or many rounds; with 392 workgroups (56 x 56) the second round is half empty and the
+    // 128 x 128 tiles at four workgroups per CU are as fast
+    bool pp = !L.xcol && !out_f32 && a.Cin % 32 == 0 && L.cout % 128 == 0 && L.hw >= 28 && (variant == 5 || variant == 0);
+    if (pp) {
+        int lw, lh, tb;
+        pick_brick(L.hw, L.hw, B, lw, lh, tb, 8);
+        const bool nt4 = L.cout % 256 == 0;
+        const long gridp = (long)(L.cout / (nt4 ? 256 : 128)) * va_cdiv(L.hw, 1 << lw) * va_cdiv(L.hw, 1 << lh) * va_cdiv(B, tb);
+        if (variant == 0) pp = VA_PP_DEFAULT && nt4 && ((gridp >= 160 && gridp <= 256) || gridp >= 1024);
+    }
+    if (pp) {
+        pick_brick(L.hw, L.hw, B, a.lgTW, a.lgTH, a.TB, 8);
+        a.tiles_x = va_cdiv(L.hw, 1 << a.lgTW);
+        a.tiles_y = va_cdiv(L.hw, 1 << a.lgTH);
+        const bool nt4 = L.cout % 256 == 0;
+        a.tiles_n = L.cout / (nt4 ? 256 : 128);
+        const unsigned gridp = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * va_cdiv(B, a.TB));
+        if (nt4) {
+            if (L.pool) k_conv3x3_pp_bf16<4, true><<<gridp, 512, 0, st>>>(a);
+            else k_conv3x3_pp_bf16<4, false><<<gridp, 512, 0, st>>>(a);
+        } else {
+            if (L.pool) k_conv3x3_pp_bf16<2, true><<<gridp, 512, 0, st>>>(a);
+            else k_conv3x3_pp_bf16<2, false><<<gridp, 512, 0, st>>>(a);
+        }
+        VA_LAUNCH_CHECK();
+        return VA_OK;
     }
     const long grid64 = (long)(L.cout / 64) * a.tiles_x * a.tiles_y * tiles_b;
     const int ksteps = 3 * a.taps_x * (a.Cin / 64);
@@ -1447,6 +1869,7 @@ extern "C" int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_di
         return fail(VA_ERR_HIP);
     }
     m->bf16_variant = 0;
+    m->bf16_first = 1;
     m->f32_conv = VA_F32_CONV_DEFAULT;
     m->train_stop_at = -1;
     if (dtype == VA_DTYPE_BF16) {
@@ -1470,7 +1893,17 @@ extern "C" int va_vgg16_create(va_ctx* ctx, int c_in, int n_classes, int desc_di
             return fail(VA_ERR_HIP);
         }
         L.xcol = bf && i == 0 && 3 * L.cin <= 64 && L.cin <= 21;
-        if (L.xcol) k_pack_conv_w_bf16_xcol<<<va_cdiv(L.cout * 192, 256), 256, 0, st>>>((const float*)conv_w[i], L.wp_bf, L.cout, L.cin);
+        if (L.xcol) {
+            k_pack_conv_w_bf16_xcol<<<va_cdiv(L.cout * 192, 256), 256, 0, st>>>((const float*)conv_w[i], L.wp_bf, L.cout, L.cin);
+            // the fused first layer (k_conv1_fused_bf16): its own packing of the same weights
+            m->f1_cp = (L.cin + 3) & ~3;
+            m->f1_krow = (3 * m->f1_cp + 15) & ~15;
+            if (hipMalloc(&m->wp_f1, (size_t)64 * 3 * m->f1_krow * sizeof(__bf16)) != hipSuccess) {
+                va_set_error("va_vgg16_create: hipMalloc failed for the first layer's weights");
+                return fail(VA_ERR_HIP);
+            }
+            k_pack_conv_w_bf16_f1<<<va_cdiv(64 * 3 * m->f1_krow, 256), 256, 0, st>>>((const float*)conv_w[i], m->wp_f1, 64, L.cin, m->f1_cp, m->f1_krow);
+        }
         else if (bf) k_pack_conv_w_bf16<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>((const float*)conv_w[i], L.wp_bf, L.cout, L.cin, L.cin_pad);
         else k_pack_conv_w<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>((const float*)conv_w[i], L.wp, L.cout, L.cin, L.cin_pad);
         if (hipMemcpyAsync(L.bias, conv_b[i], L.cout * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = VA_ERR_HIP;
@@ -1519,6 +1952,7 @@ extern "C" void va_vgg16_destroy(va_vgg16* m)
         if (m->conv[i].mom_w) (void)hipFree(m->conv[i].mom_w);
         if (m->conv[i].mom_b) (void)hipFree(m->conv[i].mom_b);
     }
+    if (m->wp_f1) (void)hipFree(m->wp_f1);
     for (int i = 0; i < 4; ++i) {
         if (m->fcw[i]) (void)hipFree(m->fcw[i]);
         if (m->fcb[i]) (void)hipFree(m->fcb[i]);
@@ -1562,7 +1996,16 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
     int cur = 1;
     if (m->dtype == VA_DTYPE_BF16) {
         // bf16 activations live in the same two ping-pong buffers (half their size is used)
-        if (m->conv[0].xcol) {
+        int first = 0;
+        if (m->conv[0].xcol && m->bf16_first == 1 && m->wp_f1 != nullptr) {
+            // the first layer straight from the NCHW input (no staged 64-channel copy of the input)
+            Conv1Args c1{x, m->wp_f1, m->conv[0].bias, (__bf16*)act[0], m->in_mean, m->in_std, B, m->c_in, m->f1_cp, m->f1_krow};
+            const unsigned g1 = (unsigned)(B * (224 / 16) * (224 / 16));
+            if (x_is_u8) k_conv1_fused_bf16<unsigned char><<<g1, 256, 0, st>>>(c1);
+            else k_conv1_fused_bf16<float><<<g1, 256, 0, st>>>(c1);
+            first = 1;
+            cur = 0;
+        } else if (m->conv[0].xcol) {
             if (x_is_u8)
                 k_nchw_to_nhwc_xcol<unsigned char><<<pgrid, 256, 0, st>>>((const unsigned char*)x, (__bf16*)act[1], B, m->c_in, 224, HW0, m->in_mean, m->in_std);
             else
@@ -1572,7 +2015,7 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
         else
             k_nchw_to_nhwc_pad<float, __bf16><<<pgrid, 256, 0, st>>>((const float*)x, (__bf16*)act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
         VA_LAUNCH_CHECK();
-        for (int i = 0; i < 13; ++i) {
+        for (int i = first; i < 13; ++i) {
             if (int rc = launch_conv_bf16(m->conv[i], m->zeros, m->bf16_variant, (const __bf16*)act[cur], act[cur ^ 1], i == 12, B, st)) return rc;
             cur ^= 1;
         }
@@ -1602,8 +2045,12 @@ extern "C" int va_vgg16_set_option(va_vgg16* m, int option, int value)
     VA_CHECK_ARG(m != nullptr, "va_vgg16_set_option: model is NULL");
     switch (option) {
         case VA_OPT_BF16_VARIANT:
-            VA_CHECK_ARG(value >= 0 && value <= 4, "va_vgg16_set_option: VA_OPT_BF16_VARIANT must be in [0,4]");
+            VA_CHECK_ARG(value >= 0 && value <= 5, "va_vgg16_set_option: VA_OPT_BF16_VARIANT must be in [0,5]");
             m->bf16_variant = value;
+            return VA_OK;
+        case VA_OPT_BF16_FIRST_LAYER:
+            VA_CHECK_ARG(value == 0 || value == 1, "va_vgg16_set_option: VA_OPT_BF16_FIRST_LAYER must be 0 or 1");
+            m->bf16_first = value;
             return VA_OK;
         case VA_OPT_F32_CONV_KERNEL:
             VA_CHECK_ARG(value == 0 || value == 1, "va_vgg16_set_option: VA_OPT_F32_CONV_KERNEL must be 0 or 1");

@@ -28,6 +28,9 @@ struct va_vgg16 {
     float* fc_mom_b[4];
     float* zeros_f32;    // >= 512 zero floats (training: bias of the linear dgrad convolutions)
     // va_vgg16_set_option (explicit A/B and test switches; nothing is read from the environment)
+    __bf16* wp_f1;      // bf16 first layer, fused kernel: [64][3][f1_krow] (NULL unless the first layer qualifies)
+    int f1_cp, f1_krow; // channels per pixel of its LDS patch (c_in rounded up to 4), elements per kernel row (16-element blocks)
+    int bf16_first;     // VA_OPT_BF16_FIRST_LAYER: 1 = fused first layer (default), 0 = input conversion + 3-step convolution
     int bf16_variant;   // VA_OPT_BF16_VARIANT: 0 = automatic tile/staging choice, 1 = 64-channel tiles + single buffer, 2 = DMA ring everywhere
     int f32_conv;       // VA_OPT_F32_CONV_KERNEL: 1 = LDS-DMA kernel where Cin % 32 == 0 (default), 0 = register-staged kernel
     int train_stop_at;  // VA_OPT_TRAIN_STOP_AT: -1 = full step; i = va_vgg16_train_step returns VA_ERR_STOPPED after conv layer i's backward
