@@ -420,6 +420,81 @@ struct ConvArgsBf {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+// Epilogue of the bf16 kernels: bias + ReLU (+ 2x2 max-pool) in fp32, then the wave's tile goes through a wave-private
+// LDS tile so that whole runs of NT * 64 bytes per pixel reach memory, 16 bytes per lane (instead of one 2-byte store
+// per value).  The MFMA operand order follows the layer:
+//   * no pooling: the WEIGHT fragment is the first operand -- accumulator (mt, nt), register 4 g4 + j of lane (r31, hh) is
+//     channel 32 nt + 8 g4 + 4 hh + j of pixel 32 mt + r31: four consecutive channels of one pixel = one 8-byte LDS write;
+//   * pooling: the PIXEL fragment is the first operand -- register 4 g4 + j is pixel 32 mt + 8 g4 + 4 hh + j of channel
+//     32 nt + r31: the four registers are one pixel quad of the brick order, their maximum one 2-byte LDS write.
+// The tile's rows are NT * 64 bytes, unpadded; the 16-byte chunk c of row r sits at chunk c ^ ((r / RPL) & (CH8 - 1)),
+// RPL = rows per 256-byte bank line: the 16 lanes of a write or read group then touch 16 different bank positions.
+// `stage`: 64 * NT * 64 bytes of LDS that no other wave touches; m0: the tile's first pixel in the workgroup's brick
+// order; nb: its first channel.
+template <bool POOL>
+constexpr bool kWeightsFirst = !POOL;
+template <int NT, bool POOL>
+__device__ __forceinline__ void epilogue_lines_bf16(const f32x16 (&acc)[2][NT], __bf16* stage, const ConvArgsBf& a, int m0, int nb,
+                                                    int X0, int Y0, int B0, int lane)
+{
+    constexpr int ROW = NT * 32, CH8 = NT * 4, RPL = NT >= 4 ? 1 : 4 / NT;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const int r31 = lane & 31, hh = lane >> 5;
+    const int H = a.H, W = a.W;
+    if constexpr (POOL) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = 32 * nt + r31;
+            const float bias = a.bias[nb + n];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[mt][nt][4 * g4 + j] + bias, 0.0f);
+                    const int row = 8 * mt + 2 * g4 + hh;  // pooled pixel (32 mt + 8 g4 + 4 hh) / 4
+                    const int col = (((n >> 3) ^ ((row / RPL) & (CH8 - 1))) << 3) | (n & 7);
+                    stage[row * ROW + col] = (__bf16)fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                }
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = 32 * nt + 8 * g4 + 4 * hh;
+                const float4 bs = *(const float4*)(a.bias + nb + n);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    bf16x4 v;
+                    v.x = (__bf16)fmaxf(acc[mt][nt][4 * g4 + 0] + bs.x, 0.0f);
+                    v.y = (__bf16)fmaxf(acc[mt][nt][4 * g4 + 1] + bs.y, 0.0f);
+                    v.z = (__bf16)fmaxf(acc[mt][nt][4 * g4 + 2] + bs.z, 0.0f);
+                    v.w = (__bf16)fmaxf(acc[mt][nt][4 * g4 + 3] + bs.w, 0.0f);
+                    const int row = 32 * mt + r31;
+                    const int col = (((n >> 3) ^ ((row / RPL) & (CH8 - 1))) << 3) | (n & 4);
+                    *(bf16x4*)(stage + row * ROW + col) = v;
+                }
+            }
+    }
+    __builtin_amdgcn_wave_barrier();  // (wave-private tile: the wave's LDS writes are ordered before its reads)
+    constexpr int ROWS = POOL ? 16 : 64;
+#pragma unroll
+    for (int it = 0; it < ROWS * CH8 / 64; ++it) {
+        const int ch = it * 64 + lane, pl = ch / CH8, c8 = ch - pl * CH8;
+        const uint4 v = *(const uint4*)(stage + pl * ROW + 8 * (c8 ^ ((pl / RPL) & (CH8 - 1))));
+        int xl, yl, bl;
+        brick_coords(m0 + (POOL ? 4 * pl : pl), a.lgTW, a.lgTH, xl, yl, bl);
+        const int x = X0 + xl, y = Y0 + yl, b = B0 + bl;
+        if (b < a.B && x < W && y < H) {
+            const size_t o = POOL ? ((((size_t)b * (H >> 1)) + (y >> 1)) * (W >> 1) + (x >> 1)) * a.Cout
+                                  : (((size_t)b * H + y) * W + x) * a.Cout;
+            *(uint4*)((__bf16*)a.out + o + nb + 8 * c8) = v;
+        }
+    }
+}
+
 // 128 pixels x (NT*64) channels per workgroup of 4 waves (2 x 2), wave tile 64 x (NT*32).
 //
 // Staging: LDS-DMA (global_load_lds_dwordx4), no staging registers and no ds_write pass.  One wave
@@ -554,7 +629,8 @@ __device__ __forceinline__ void conv3x3_mfma_bf16_body(const ConvArgsBf& a)
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = (OUT_F32 || !kWeightsFirst<POOL>) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0)
+                                                                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
         }
     };
     if constexpr (NBUF == 1) {
@@ -590,6 +666,15 @@ __device__ __forceinline__ void conv3x3_mfma_bf16_body(const ConvArgsBf& a)
         }
     }
 
+    if constexpr (!OUT_F32) {
+        // (weights as the MFMA's first operand: a lane owns channel quads of one pixel) whole lines through LDS
+        if constexpr (NBUF != 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave has read the last tile: the ring becomes the staging tiles
+        }
+        epilogue_lines_bf16<NT, POOL>(acc, smem + wave * 64 * NT * 32, a, wm * MT * 32, n0 + wn * NT * 32, X0, Y0, B0, lane);
+        return;
+    }
     // epilogue: bias + ReLU (+ 2x2 max-pool over the 4 registers reg&3 of a lane), fp32 math, bf16/f32 store
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -703,18 +788,41 @@ __global__ void __launch_bounds__(256) k_conv1_fused_bf16(Conv1Args a)
         *(uint4*)(wl + n * WS + 8 * r) = ((const uint4*)a.wp)[i];
     }
     __syncthreads();
+    // the patch: rows of 18 pixels starting at x = X0 - 1, fetched as the six ALIGNED groups of four pixels that cover
+    // [X0 - 4, X0 + 20) (a group is wholly inside or wholly outside the image); U groups in flight per thread
     const TIN* const xin = (const TIN*)a.x + (size_t)b * C * H * W;
-    for (int i = tid; i < NPIX * C; i += 256) {
-        const int c = i / NPIX, p = i - c * NPIX;
-        const int py = p / PW, px = p - py * PW;
-        const int gy = Y0 - 1 + py, gx = X0 - 1 + px;
-        float v = 0.0f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const TIN raw = xin[((size_t)c * H + gy) * W + gx];
-            if constexpr (sizeof(TIN) == 1) v = ((float)raw / 255.0f - a.mean[c]) / a.stdv[c];
-            else v = (float)raw;
+    typedef TIN tin4 __attribute__((ext_vector_type(4)));
+    constexpr int U = 3;
+    const int items = C * PW * 6;
+    for (int i0 = 0; i0 < items; i0 += 256 * U) {
+        tin4 raw[U];
+        int dst[U], cc[U], q4[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256 + tid;
+            const int c = i / (PW * 6), r = i - c * (PW * 6), py = r / 6, q = r - py * 6;
+            const int gy = Y0 - 1 + py, gx = X0 - 4 + 4 * q;
+            ok[u] = i < items && gy >= 0 && gy < H && gx >= 0 && gx < W;  // (outside the image the patch stays zero)
+            raw[u] = tin4{0, 0, 0, 0};
+            if (ok[u]) raw[u] = *(const tin4*)(xin + ((size_t)c * H + gy) * W + gx);
+            cc[u] = c;
+            q4[u] = 4 * q - 3;                       // patch column of the group's first pixel
+            dst[u] = (py * PW + q4[u]) * Cp + c;
         }
-        patch[p * Cp + c] = (__bf16)v;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int px = q4[u] + e;
+                if (px < 0 || px >= PW) continue;
+                float v;
+                if constexpr (sizeof(TIN) == 1) v = ((float)raw[u][e] / 255.0f - a.mean[cc[u]]) / a.stdv[cc[u]];
+                else v = (float)raw[u][e];
+                patch[dst[u] + e * Cp] = (__bf16)v;
+            }
+        }
     }
     __syncthreads();
 
@@ -1145,7 +1253,8 @@ __device__ __forceinline__ void conv3x3_pp_body(const ConvArgsBf& a)
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][ks], fb[nt][ks], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = kWeightsFirst<POOL> ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[nt][ks], fa[mt][ks], acc[mt][nt], 0, 0, 0)
+                                                      : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][ks], fb[nt][ks], acc[mt][nt], 0, 0, 0);
         if (g == 0) sync(inflight);       // before group 0's own L(t + 1) (and group 1's C(t))
         else if (MAIN || t + 1 < T) sync(3);  // group 1 has no partner phase after its last C
     };
@@ -1153,42 +1262,9 @@ __device__ __forceinline__ void conv3x3_pp_body(const ConvArgsBf& a)
     for (; t < T - D; ++t) step(t, std::true_type{});
     for (; t < T; ++t) step(t, std::false_type{});
 
-    // epilogue: bias + ReLU (+ 2x2 max-pool over the 4 registers reg&3 of a lane), fp32 math, bf16 store
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + (wn * NT + nt) * 32 + r31;
-        const float bias = a.bias[n];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int mbase = 128 * g + (wm * MT + mt) * 32 + 8 * g4 + 4 * hh;
-                int xl, yl, bl;
-                brick_coords(mbase, a.lgTW, a.lgTH, xl, yl, bl);
-                const int x = X0 + xl, y = Y0 + yl, b = B0 + bl;
-                if (b >= a.B) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[mt][nt][4 * g4 + j] + bias, 0.0f);
-                if constexpr (POOL) {
-                    if (x < W && y < H) {
-                        const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                        const size_t o = ((((size_t)b * (H >> 1)) + (y >> 1)) * (W >> 1) + (x >> 1)) * a.Cout + n;
-                        ((__bf16*)a.out)[o] = (__bf16)mx;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int xx = x + (j & 1), yy = y + (j >> 1);
-                        if (xx < W && yy < H) {
-                            const size_t o = (((size_t)b * H + yy) * W + xx) * a.Cout + n;
-                            ((__bf16*)a.out)[o] = (__bf16)v[j];
-                        }
-                    }
-                }
-            }
-        }
-    }
+    // epilogue (after barrier 2T nobody reads the ring any more: group 1's last L phase lies before it): bias, ReLU, pool,
+    // whole lines through this wave's 64 x (NT * 64)-byte share of the ring
+    epilogue_lines_bf16<NT, POOL>(acc, (__bf16*)smem + wave * 64 * NT * 32, a, 128 * g + wm * MT * 32, n0 + wn * NT * 32, X0, Y0, B0, lane);
 }
 
 // (the body is a __device__ function: buffer-resource builtins in a __global__ template body keep the host pass from
