@@ -90,13 +90,14 @@ size_t va_vgg16_workspace_bytes(const va_vgg16* model, int batch);
 
 /*
  * A/B and test switches of ONE model handle (defaults are the measured choices of DESIGN.md; results of the
- * fp32 path do not depend on VA_OPT_F32_CONV_KERNEL, the three bf16 variants are bit-identical to each other):
- *   VA_OPT_BF16_VARIANT     0 (default) tile and staging scheme chosen per layer; 1 = 64-channel tiles with one
- *                           LDS buffer on every layer; 2 = the LDS-DMA ring on every layer; 5 = the two-group kernel (k_conv3x3_pp_bf16)
- *                           on the layers with >= 128 output channels and >= 28x28 pixels; 3 / 4 = the halo-brick
- *                           kernel on the layers of 28x28 pixels and more (8 waves with 64-pixel wave tiles / 4 waves
- *                           with 128-pixel wave tiles; chunk-major K order: another fp32 summation order, so within
- *                           bf16 noise of 0..2 rather than bit-identical; measured no faster)
+ * fp32 path do not depend on VA_OPT_F32_CONV_KERNEL):
+ *   VA_OPT_BF16_VARIANT     0 (default) kernel, tile and staging scheme chosen per layer (measured); 1 = 64-channel
+ *                           tiles with one LDS buffer on every layer; 2 = the LDS-DMA ring on every layer; 5 = the
+ *                           two-group kernel (k_conv3x3_pp_bf16) on every layer with >= 128 output channels and >= 28x28
+ *                           pixels (the default uses it on the 28x28 layers); 0, 1, 2 and 5 add the same products in the
+ *                           same order and agree bit for bit.  6 = the two-group kernel on halo bricks
+ *                           (k_conv3x3_bpp_bf16; chunk-major K order: another fp32 summation order, so within bf16 noise
+ *                           of the others; measured no faster).  (3 and 4, round 2's first halo-brick kernel, are gone.)
  *   VA_OPT_BF16_FIRST_LAYER 1 (default) the first layer reads the NCHW input itself (k_conv1_fused_bf16); 0 = the input is
  *                           first staged as a 64-channel NHWC tensor and convolved in three K steps (the round-1 path;
  *                           another fp32 summation order: bf16-level agreement).  Independent of VA_OPT_BF16_VARIANT

@@ -135,6 +135,26 @@ def test_full_batch_properties():
     pipe.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_precomputed_flow_volumes_run_the_two_models_side_by_side(dtype):
+    # with flow volumes given, the temporal model runs on a second stream beside the spatial one: same scores as the two
+    # models called one after the other, batch after batch (each model owns its workspace; an event guards its reuse)
+    from video_analytics_amd import pipeline, synth
+    rgb, _, _ = synth.synth_clips(6, seed=21)
+    g = torch.Generator().manual_seed(5)
+    stack = torch.randn(6, 20, 224, 224, generator=g)
+    pipe = pipeline.TwoStreamPipeline(device=0, cnn_dtype=dtype)
+    rgb_d, stack_d = rgb.cuda(), stack.cuda()
+    ref_s = pipe.spatial.forward(rgb_d)[2].clone()
+    ref_t = pipe.temporal.forward(stack_d)[2].clone()
+    torch.cuda.synchronize()
+    outs = [pipe.submit(rgb_d, flow_stack=stack_d) for _ in range(3)]
+    pipe.wait()
+    for o in outs:
+        assert torch.equal(o["logits_s"], ref_s) and torch.equal(o["logits_t"], ref_t)
+    pipe.close()
+
+
 def test_concurrent_flow_streams_give_identical_results():
     from video_analytics_amd import flow as vflow, synth
     _, gray, _ = synth.synth_clips(5, seed=6, n_gray=4)

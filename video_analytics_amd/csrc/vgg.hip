@@ -22,6 +22,7 @@
 //     FC1's weight is repacked so that the NHWC feature map can be used without a transpose while
 //     keeping the reference's CHW-major flatten order c*49+h*7+w (Sheet03/spatialModel.py:213).
 #include "vgg_internal.h"
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -894,207 +895,6 @@ __global__ void __launch_bounds__(256) k_conv1_fused_bf16(Conv1Args a)
     }
 }
 
-// ---------------------------------------------------------------- bf16 conv3x3, halo brick in LDS -------
-//
-// The kernel above fetches an A tile (pixels x 64 channels) per TAP: nine DMA passes over (nearly) the same pixels, 8
-// LDS-DMA instructions per wave for 16 MFMAs, and nine L2/Infinity-Cache reads of every activation.  Here a workgroup
-// stages, once per 64-channel chunk, the HALO BRICK of its 256 output pixels -- TB images x (TH + 2) x (TW + 2) pixels,
-// one 128-byte LDS row per pixel -- and forms the A fragment of each of the nine taps by shifting the row index
-// (row(m, ky, kx) = row(m, 0, 0) + ky (TW + 2) + kx; out-of-image pixels are zero rows).  Per 64-channel chunk a wave
-// issues <= 7 DMA pieces for the brick and NT per tap for the weights: ~2.7 per 16 MFMAs instead of 8, and the
-// activations are read from memory once instead of nine times.
-//   * 8 waves = 4 (pixels) x 2 (channels), wave tile 64 x (NT * 32), workgroup tile 256 pixels x (NT * 64) channels;
-//   * K order: chunk-major, taps inside (the kernel above: tap-major) -- a different fp32 summation order;
-//   * A brick double-buffered (the next chunk's brick lands during the nine tap steps), B double-buffered with the next
-//     step's weights in flight during the MFMAs; ONE barrier per step; waits are counted (s_waitcnt vmcnt) so that the
-//     brick stays in flight across the step that follows its issue;
-//   * same source-side bank swizzle as above, keyed on the LDS row: lane (row r, slot p) of a DMA piece fetches chunk
-//     p ^ ((r >> 1) & 7); a fragment read of chunk c of row R goes to slot c ^ ((R >> 1) & 7).  The 32 rows of a fragment
-//     are two (TW >= 16) or four runs of consecutive brick rows, not 32 consecutive rows: a few 2-way bank conflicts
-//     per read remain (measured, not modelled).
-// One workgroup per CU (96-112 KB of brick + 32 KB of weights), two waves per SIMD.
-// MT = 2: 8 waves (4 x 2), wave tile 64 x NT*32; MT = 4: 4 waves (2 x 2), wave tile 128 x NT*32 (each B fragment feeds
-// four MFMAs instead of two: 0.75 KB of LDS reads per MFMA instead of 1).
-template <int LGTW, int LGTH, int NT, bool POOL, bool OUT_F32, int MT = 2>
-__global__ void __launch_bounds__(2048 / MT) k_conv3x3_brick_bf16(ConvArgsBf a)
-{
-    constexpr int TW = 1 << LGTW, TH = 1 << LGTH, BM = 256, TB = BM / (TW * TH), PW = TW + 2, PH = TH + 2;
-    static_assert(TW * TH * TB == BM && TB >= 1, "the brick must hold 256 output pixels");
-    constexpr int NWAVES = 16 / MT;               // waves of the workgroup (two of them along the channels)
-    constexpr int NR = TB * PH * PW;              // halo brick rows (one pixel each)
-    constexpr int NA = (NR + 8 * NWAVES - 1) / (8 * NWAVES);  // DMA pieces (8 rows) per wave and chunk
-    constexpr int A_ROWS = NWAVES * NA * 8;       // rows of one A buffer (rows >= NR: zero filler)
-    constexpr int BN = NT * 64;
-    constexpr int NBP = BN / (8 * NWAVES);        // weight pieces per wave and step
-    constexpr int A_ELEMS = A_ROWS * kBfBK, B_ELEMS = BN * kBfBK;
-    __shared__ __attribute__((aligned(1024))) __bf16 smem[2 * A_ELEMS + 2 * B_ELEMS];
-    __bf16* const sAbuf = smem;
-    __bf16* const sBbuf = smem + 2 * A_ELEMS;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int n_tile = bid % a.tiles_n;
-    bid /= a.tiles_n;
-    const int tile_x = bid % a.tiles_x;
-    bid /= a.tiles_x;
-    const int tile_y = bid % a.tiles_y;
-    const int tile_b = bid / a.tiles_y;
-    const int n0 = n_tile * BN;
-    const int H = a.H, W = a.W, Cin = a.Cin;
-    const int X0 = tile_x << LGTW, Y0 = tile_y << LGTH, B0 = tile_b * TB;
-
-    // loader role: row (lane >> 3) of an 8-row piece, 16-byte slot (lane & 7)
-    const int lrow = lane >> 3, lslot = lane & 7;
-    int aoff[NA];       // element offset of this lane's 16 bytes of brick row R (channel 0 of the chunk)
-    unsigned aok = 0u;  // bit i: piece i of this lane reads a pixel inside the image
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int R = (wave * NA + i) * 8 + lrow;
-        const int b = R / (PH * PW), rem = R - b * (PH * PW);
-        const int yy = rem / PW, xx = rem - yy * PW;
-        const int y = Y0 + yy - 1, x = X0 + xx - 1, bb = B0 + b;
-        const bool ok = R < NR && bb < a.B && y >= 0 && y < H && x >= 0 && x < W;
-        aok |= ok ? (1u << i) : 0u;
-        aoff[i] = ok ? ((bb * H + y) * W + x) * Cin + 8 * (lslot ^ ((R >> 1) & 7)) : 0;
-    }
-    const __bf16* wrow[NBP];
-#pragma unroll
-    for (int i = 0; i < NBP; ++i) {
-        const int row = (wave * NBP + i) * 8 + lrow;
-        wrow[i] = a.wp + (size_t)(n0 + row) * 9 * Cin + 8 * (lslot ^ ((row >> 1) & 7));
-    }
-    auto stage_a = [&](int buf, int c0) {
-        __bf16* const sA = sAbuf + buf * A_ELEMS;
-        static_for<NA>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            const __bf16* src = ((aok >> i) & 1u) ? a.in + aoff[i] + c0 : a.zeros;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sA + (wave * NA + i) * 8 * kBfBK), 16, 0, 0);
-        });
-    };
-    auto stage_b = [&](int buf, int tap, int c0) {
-        __bf16* const sB = sBbuf + buf * B_ELEMS;
-        static_for<NBP>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wrow[i] + (size_t)tap * Cin + c0),
-                                             (lds_ptr_t)(sB + (wave * NBP + i) * 8 * kBfBK), 16, 0, 0);
-        });
-    };
-
-    // fragment role
-    const int r31 = lane & 31, hh = lane >> 5;
-    int idx0[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int xl, yl, bl;
-        brick_coords((wm * MT + mt) * 32 + r31, LGTW, LGTH, xl, yl, bl);
-        idx0[mt] = (bl * PH + yl + 1) * PW + xl + 1;
-    }
-    const int fswb = (r31 >> 1) & 7;  // B fragment rows are (multiple of 32) + r31
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
-
-    const int cchunks = Cin / kBfBK, T = 9 * cchunks;
-    stage_a(0, 0);
-    stage_b(0, 0, 0);
-    int tap = 0, chunk = 0, abuf = 0;
-    bool brick_in_flight = false;  // the previous step issued a brick after its weights
-    for (int t = 0; t < T; ++t) {
-        // this wave's DMAs of step t (and, at tap 0, of the chunk's brick) have landed; a brick issued in the previous
-        // step (behind that step's weights) may stay in flight
-        if (brick_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave's pieces of step t are in LDS; step t-1's reads are done
-        int ntap = tap + 1, nchunk = chunk;
-        if (ntap == 9) {
-            ntap = 0;
-            ++nchunk;
-        }
-        if (t + 1 < T) stage_b((t + 1) & 1, ntap, nchunk * kBfBK);
-        brick_in_flight = false;
-        if (tap == 0 && chunk + 1 < cchunks) {
-            stage_a(abuf ^ 1, (chunk + 1) * kBfBK);
-            brick_in_flight = true;
-        }
-        {
-            const __bf16* const sA = sAbuf + abuf * A_ELEMS;
-            const __bf16* const sB = sBbuf + (t & 1) * B_ELEMS;
-            const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
-            const int toff = ky * PW + kx;
-            int ia[MT], swa[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                ia[mt] = idx0[mt] + toff;
-                swa[mt] = (ia[mt] >> 1) & 7;
-            }
-#pragma unroll
-            for (int ks = 0; ks < kBfBK / 16; ++ks) {
-                bf16x8 fa[MT], fb[NT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    fa[mt] = *reinterpret_cast<const bf16x8*>(&sA[ia[mt] * kBfBK + ((2 * ks + hh) ^ swa[mt]) * 8]);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    fb[nt] = *reinterpret_cast<const bf16x8*>(&sB[((wn * NT + nt) * 32 + r31) * kBfBK + ((2 * ks + hh) ^ fswb) * 8]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
-            }
-        }
-        if (tap == 8) abuf ^= 1;
-        tap = ntap;
-        chunk = nchunk;
-    }
-
-    // epilogue: bias + ReLU (+ 2x2 max-pool over the 4 registers reg&3 of a lane), fp32 math, bf16/f32 store
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + (wn * NT + nt) * 32 + r31;
-        const float bias = a.bias[n];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int mbase = (wm * MT + mt) * 32 + 8 * g4 + 4 * hh;
-                int xl, yl, bl;
-                brick_coords(mbase, LGTW, LGTH, xl, yl, bl);
-                const int x = X0 + xl, y = Y0 + yl, b = B0 + bl;
-                if (b >= a.B) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[mt][nt][4 * g4 + j] + bias, 0.0f);
-                if constexpr (POOL) {
-                    if (x < W && y < H) {
-                        const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                        const size_t o = ((((size_t)b * (H >> 1)) + (y >> 1)) * (W >> 1) + (x >> 1)) * a.Cout + n;
-                        if constexpr (OUT_F32) ((float*)a.out)[o] = mx;
-                        else ((__bf16*)a.out)[o] = (__bf16)mx;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int xx = x + (j & 1), yy = y + (j >> 1);
-                        if (xx < W && yy < H) {
-                            const size_t o = (((size_t)b * H + yy) * W + xx) * a.Cout + n;
-                            if constexpr (OUT_F32) ((float*)a.out)[o] = v[j];
-                            else ((__bf16*)a.out)[o] = (__bf16)v[j];
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------- bf16 conv3x3, two wave groups in turns ------
 //
 // k_conv3x3_pp_bf16: 512 threads = two GROUPS of four waves (one wave of each group on every SIMD).  The workgroup tile is
@@ -1273,6 +1073,198 @@ template <int NT, bool POOL>
 __global__ void __launch_bounds__(512) k_conv3x3_pp_bf16(ConvArgsBf a)
 {
     conv3x3_pp_body<NT, POOL>(a);
+}
+
+// ---------------------------------------------------------------- bf16 conv3x3, two wave groups + halo brick -------
+//
+// An experiment kept as a tested option (VA_OPT_BF16_VARIANT 6), not a default.  Tap-major staging moves (pixels +
+// channels) x 64 B per 32-channel step: 32 KB per step of the 256 x 256 tile, and a CU took in 27..29 B/clk when every
+// CU staged and did nothing else (k_conv3x3_pp_bf16 with its reads and MFMAs removed; LDS-DMA and register loads alike).
+// k_conv3x3_bpp_bf16 keeps the two-group schedule and removes most of the activation traffic: per 32-channel CHUNK the
+// workgroup stages the halo brick of its 256 output pixels ONCE -- TB images x (TH + 2) x (TW + 2) pixels, one 64-byte
+// LDS row each, double-buffered -- and runs the nine taps on it by shifting the fragment's row index; only the weights
+// (NT * 4 KB per step, ring of four) are staged per step: 18 KB instead of 32 KB per step (16 x 16 bricks).
+// Measured (B = 32, us per layer, this kernel / the defaults): 28 x 28: 94 / 85 and 120 / 109 (pooled); 56 x 56: 102 / 95
+// and 126 / 117; 112 x 112: 80 / 80 and 128 / 118 -- 43 % fewer staged bytes and no gain: the steps are not bound by
+// the bytes taken in but by the serial parts of a phase (fragment reads -> barrier, the phase's skew), DESIGN.md.
+//   * K order: chunk-major (32 channels), the nine taps inside -- not the summation order of the tap-major kernels:
+//     agreement at the bf16 level (tested), not bit for bit;
+//   * waits: the brick of chunk c + 1 is issued at tap 0 of chunk c, BEFORE that step's weight tile; loads complete in
+//     issue order, so the counted waits of the weight ring cover it (it must have landed by tap 2; the two steps in
+//     between allow NA more operations in flight);
+//   * the bank swizzle is keyed on the LDS row as above (chunk c of row r at slot c ^ ((r >> 2) & 3)); a fragment's 32
+//     rows are brick-ordered pixels shifted by the tap, not 32 consecutive rows: two of the sixteen lanes of a read group
+//     can share a bank position (2-way on those; measured, not modelled).
+template <int LGTW, int LGTH, int NT, bool POOL>
+__device__ __forceinline__ void conv3x3_bpp_body(const ConvArgsBf& a)
+{
+    constexpr int TW = 1 << LGTW, TH = 1 << LGTH, BM = 256, TB = BM / (TW * TH), PW = TW + 2, PH = TH + 2;
+    static_assert(TW * TH * TB == BM && TB >= 1, "the brick must hold 256 output pixels");
+    constexpr int BN = NT * 64, MT = 2, KB = 32, NB = 4, D = 3, ROWB = KB * 2;
+    constexpr int NR = TB * PH * PW;                    // halo brick rows (one pixel each)
+    constexpr int NA = (NR + 127) / 128;                // brick pieces (16 rows) per wave and chunk
+    constexpr int A_ROWS = 8 * NA * 16;                 // rows of one brick buffer (rows >= NR: zero filler)
+    constexpr int A_BYTES = A_ROWS * ROWB, B_BYTES = BN * ROWB;
+    constexpr int BPW = BN / 128;                       // weight pieces per wave and step
+    static_assert(BN % 128 == 0, "every wave stages whole pieces of the weight tile");
+    constexpr int RING_BYTES = 2 * A_BYTES + NB * B_BYTES, EPI_BYTES = 8 * 64 * NT * 64;  // (the epilogue's staging tiles reuse the ring)
+    __shared__ __attribute__((aligned(1024))) char smem[RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES];
+    char* const sAbuf = smem;
+    char* const sBbuf = smem + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, q = wave & 3, wm = q >> 1, wn = q & 1;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_tile = bid % a.tiles_n;
+    bid /= a.tiles_n;
+    const int tile_x = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int tile_y = bid % a.tiles_y;
+    const int tile_b = bid / a.tiles_y;
+    const int n0 = n_tile * BN;
+    const int H = a.H, W = a.W, Cin = a.Cin;
+    const int X0 = tile_x << LGTW, Y0 = tile_y << LGTH, B0 = tile_b * TB;
+
+    // loader role: row (lane >> 2) of a 16-row piece, slot (lane & 3).  Buffer loads to LDS; a brick row outside the image
+    // (or beyond the brick) carries an out-of-range offset, for which the load writes zeros
+    const int lrow = lane >> 2, lchunk = (lane & 3) ^ ((lrow >> 2) & 3);
+    const __amdgpu_buffer_rsrc_t rs_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.in), 0, (int)((long)a.B * H * W * Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wp), 0, (int)((long)a.Cout * 9 * Cin * 2), 0x00020000);
+    int aoff[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int R = (wave * NA + i) * 16 + lrow;
+        const int b = R / (PH * PW), rem = R - b * (PH * PW);
+        const int yy = rem / PW, xx = rem - yy * PW;
+        const int y = Y0 + yy - 1, x = X0 + xx - 1, bb = B0 + b;
+        const bool ok = R < NR && bb < a.B && y >= 0 && y < H && x >= 0 && x < W;
+        aoff[i] = ok ? (int)(((((long)bb * H + y) * W + x) * Cin + 8 * lchunk) * 2) : 0x7fffffff;
+    }
+    int boff[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) boff[i] = (int)(((long)(n0 + (wave * BPW + i) * 16 + lrow) * 9 * Cin + 8 * lchunk) * 2);
+
+    // fragment role: brick row of this lane's pixel at tap (0, 0)
+    const int r31 = lane & 31, hh = lane >> 5, fswb = (r31 >> 2) & 3;
+    int idx0[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int xl, yl, bl;
+        brick_coords(128 * g + (wm * MT + mt) * 32 + r31, LGTW, LGTH, xl, yl, bl);
+        idx0[mt] = (bl * PH + yl + 1) * PW + xl + 1;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    const int nchunks = Cin / KB, T = 9 * nchunks;
+    // the next weight tile to stage: tap, chunk, ring slot
+    int stap = 0, schunk = 0, sbuf = 0;
+    auto stage_b = [&]() {
+        char* const sB = sBbuf + sbuf * B_BYTES;
+        const int so = (stap * Cin + schunk * KB) * 2;
+        static_for<BPW>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(sB + (wave * BPW + i) * 16 * ROWB), 16, boff[i], so, 0, 0);
+        });
+        ++stap;
+        if (stap == 9) {
+            stap = 0;
+            ++schunk;
+        }
+        sbuf = sbuf + 1 == NB ? 0 : sbuf + 1;
+    };
+    auto stage_a = [&](int chunk) {
+        char* const sA = sAbuf + (chunk & 1) * A_BYTES;
+        static_for<NA>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(sA + (wave * NA + i) * 16 * ROWB), 16, aoff[i], chunk * KB * 2, 0, 0);
+        });
+    };
+    // wait until at most `ops` of this wave's loads are still in flight, and its LDS reads are done; then the barrier
+    auto sync = [&](int ops) {
+        if (ops < 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (ops == 2 * BPW + NA) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * BPW + NA) : "memory");
+        else if (ops == 2 * BPW) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * BPW) : "memory");
+        else if (ops == BPW) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(BPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    stage_a(0);
+    for (int j = 0; j < D; ++j) stage_b();  // (T >= 18 > D)
+    sync(2 * BPW);                          // the first brick and step 0's weights have landed
+    if (g == 1) sync(-1);                   // group 1 starts half a step later
+
+    bf16x8 fa[MT][KB / 16] = {}, fb[NT][KB / 16] = {};
+    int rbuf = 0, tap = 0, chunk = 0;
+    auto step = [&](const int t, auto main_tag) __attribute__((always_inline)) {
+        constexpr bool MAIN = decltype(main_tag)::value;
+        {
+            const char* const sA = sAbuf + (chunk & 1) * A_BYTES;
+            const char* const sB = sBbuf + rbuf * B_BYTES;
+            const int ky = tap / 3, toff = (ky - 1) * PW + (tap - 3 * ky) - 1;
+            int arow[MT], asw[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                arow[mt] = idx0[mt] + toff;
+                asw[mt] = (arow[mt] >> 2) & 3;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KB / 16; ++ks) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    fa[mt][ks] = *reinterpret_cast<const bf16x8*>(sA + arow[mt] * ROWB + ((2 * ks + hh) ^ asw[mt]) * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    fb[nt][ks] = *reinterpret_cast<const bf16x8*>(sB + ((wn * NT + nt) * 32 + r31) * ROWB + ((2 * ks + hh) ^ fswb) * 16);
+            }
+            rbuf = rbuf + 1 == NB ? 0 : rbuf + 1;
+        }
+        const bool brick = tap == 0 && chunk + 1 < nchunks;
+        if (brick) stage_a(chunk + 1);  // (before this step's weight tile: loads complete in issue order)
+        if (MAIN || t + D < T) stage_b();
+        // loads that may stay in flight at the barrier before the ring's next reader: the weight tiles t + 2 .. min(t + D,
+        // T - 1), plus the brick while it is younger than the tile the reader needs (taps 0 and 1)
+        const int steps = MAIN ? D - 1 : (t + D < T ? D - 1 : T - 2 - t < 0 ? 0 : T - 2 - t);
+        const int inflight = steps * BPW + ((tap < 2 && chunk + 1 < nchunks) ? NA : 0);
+        if (g == 0) sync(-1);
+        else sync(inflight);
+#pragma unroll
+        for (int ks = 0; ks < KB / 16; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = kWeightsFirst<POOL> ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[nt][ks], fa[mt][ks], acc[mt][nt], 0, 0, 0)
+                                                      : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][ks], fb[nt][ks], acc[mt][nt], 0, 0, 0);
+        if (g == 0) sync(inflight);
+        else if (MAIN || t + 1 < T) sync(-1);
+        ++tap;
+        if (tap == 9) {
+            tap = 0;
+            ++chunk;
+        }
+    };
+    int t = 0;
+    for (; t < T - D; ++t) step(t, std::true_type{});
+    for (; t < T; ++t) step(t, std::false_type{});
+
+    // epilogue (after barrier 2T nobody reads the LDS tiles any more): whole lines through this wave's share of them
+    epilogue_lines_bf16<NT, POOL>(acc, (__bf16*)smem + wave * 64 * NT * 32, a, 128 * g + wm * MT * 32, n0 + wn * NT * 32, X0, Y0, B0, lane);
+}
+
+template <int LGTW, int LGTH, int NT, bool POOL>
+__global__ void __launch_bounds__(512) k_conv3x3_bpp_bf16(ConvArgsBf a)
+{
+    conv3x3_bpp_body<LGTW, LGTH, NT, POOL>(a);
 }
 
 // ---------------------------------------------------------------- fp32 conv3x3, LDS-DMA staging ---------
@@ -1604,11 +1596,11 @@ constexpr long VA_WIDE_MIN = 512;           // register-staged fp32 kernel: 128-
 constexpr int VA_RING = 3;                  // depth of the LDS-DMA ring (two workgroups per CU)
 constexpr long VA_RING_MAXGRID = 1024;      // bf16: ring + 64-channel tiles below this many workgroups (the 14x14 layers)
 constexpr long VA_RING_MAXGRID_F32 = 1024;  // fp32: the same threshold (0 and 4096 measured 2-4 % slower)
+#ifndef VA_BPP_DEFAULT
+#define VA_BPP_DEFAULT 0    // bf16: 1 = the two-group halo-brick kernel wherever it applies (set after measurement)
+#endif
 #ifndef VA_PP_DEFAULT
 #define VA_PP_DEFAULT 1     // bf16: the two-group kernel where launch_conv_bf16 measured it faster (0: never by default)
-#endif
-#ifndef VA_BRICK_DEFAULT
-#define VA_BRICK_DEFAULT 0  // bf16: 1 = the halo-brick kernel wherever it applies (set after measurement)
 #endif
 constexpr int VA_F32_CONV_DEFAULT = 1;      // 1: LDS-DMA fp32 kernel where Cin % 32 == 0; va_vgg16_set_option(VA_OPT_F32_CONV_KERNEL, 0) selects the register-staged one (A/B)
 constexpr int VA_CIN_ALIGN = 16;            // fp32 first-layer channel padding (3 -> 16: register-staged kernel; 20 -> 32: DMA kernel)
@@ -1716,44 +1708,6 @@ int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const
     //  - few (14x14 and, with VA_RING_MAXGRID, 28x28 layers): 64-channel tiles and the 3-deep DMA ring at
     //    two workgroups per CU (all workgroups resident at once);
     //  - many: 128-channel tiles, single buffer, four workgroups per CU.
-    // variant 3 (and the default where measured faster): the halo-brick kernel on the layers whose 256-pixel bricks fill
-    // the image and whose grid covers the GPU (224^2 / 112^2: 16x16 bricks; 56^2: 8x8 bricks of 4 images; 28^2: 32x4 of 2)
-    if ((variant == 3 || variant == 4 || (variant == 0 && VA_BRICK_DEFAULT)) && !L.xcol && !out_f32 && a.Cin % 64 == 0 && L.hw >= 28) {
-        const int lgw = L.hw >= 112 ? 4 : L.hw == 56 ? 3 : 5, lgh = L.hw >= 112 ? 4 : L.hw == 56 ? 3 : 2;
-        const int tb = 256 >> (lgw + lgh);
-        const bool nt2 = L.cout % 128 == 0;
-        a.lgTW = lgw;
-        a.lgTH = lgh;
-        a.TB = tb;
-        a.tiles_x = va_cdiv(L.hw, 1 << lgw);
-        a.tiles_y = va_cdiv(L.hw, 1 << lgh);
-        a.tiles_n = L.cout / (nt2 ? 128 : 64);
-        const unsigned gridb = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * va_cdiv(B, tb));
-        bool done = true;
-#define VA_LAUNCH_BRICK(W_, H_, NT_)                                                                     \
-    {                                                                                                    \
-        if (variant == 4) {                                                                              \
-            if (L.pool) k_conv3x3_brick_bf16<W_, H_, NT_, true, false, 4><<<gridb, 256, 0, st>>>(a);     \
-            else k_conv3x3_brick_bf16<W_, H_, NT_, false, false, 4><<<gridb, 256, 0, st>>>(a);           \
-        } else {                                                                                         \
-            if (L.pool) k_conv3x3_brick_bf16<W_, H_, NT_, true, false, 2><<<gridb, 512, 0, st>>>(a);     \
-            else k_conv3x3_brick_bf16<W_, H_, NT_, false, false, 2><<<gridb, 512, 0, st>>>(a);           \
-        }                                                                                                \
-    }
-        if (lgw == 4 && nt2) VA_LAUNCH_BRICK(4, 4, 2)
-        else if (lgw == 4) VA_LAUNCH_BRICK(4, 4, 1)
-        else if (lgw == 3 && nt2) VA_LAUNCH_BRICK(3, 3, 2)
-        else if (lgw == 5 && nt2) VA_LAUNCH_BRICK(5, 2, 2)
-        else done = false;
-#undef VA_LAUNCH_BRICK
-        if (done) {
-            VA_LAUNCH_CHECK();
-            return VA_OK;
-        }
-        pick_brick(L.hw, L.hw, B, a.lgTW, a.lgTH, a.TB);
-        a.tiles_x = va_cdiv(L.hw, 1 << a.lgTW);
-        a.tiles_y = va_cdiv(L.hw, 1 << a.lgTH);
-    }
     // The two-group kernel (k_conv3x3_pp_bf16).  variant 5: on every layer with >= 128 output channels and at least
     // 28 x 28 pixels.  Default: where it measured faster (B = 32, profiles/README.md): the 256-channel tiles whose grid of
     // 256-pixel x 256-channel workgroups is ONE round of the 256 CUs (the 28 x 28 layers: 196 workgroups, 105 / 107 us
@@ -1784,9 +1738,35 @@ int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const
         VA_LAUNCH_CHECK();
         return VA_OK;
     }
+    // variant 6: the two-group kernel on halo bricks (k_conv3x3_bpp_bf16) on the layers with >= 128 output channels and
+    // 28 x 28 pixels or more (16 x 16 bricks; 8 x 8 of four images; 4 x 4 of sixteen)
+    if ((variant == 6 || (variant == 0 && VA_BPP_DEFAULT)) && !L.xcol && !out_f32 && a.Cin % 32 == 0 && L.cout % 128 == 0 &&
+        (L.hw == 224 || L.hw == 112 || L.hw == 56 || L.hw == 28)) {
+        const int lg = L.hw >= 112 ? 4 : L.hw == 56 ? 3 : 2;
+        a.lgTW = a.lgTH = lg;
+        a.TB = 256 >> (2 * lg);
+        a.tiles_x = a.tiles_y = L.hw >> lg;
+        const bool nt4 = L.cout % 256 == 0;
+        a.tiles_n = L.cout / (nt4 ? 256 : 128);
+        const unsigned gridb = (unsigned)(a.tiles_n * a.tiles_x * a.tiles_y * va_cdiv(B, a.TB));
+#define VA_LAUNCH_BPP(LG_, NT_)                                                              \
+    {                                                                                        \
+        if (L.pool) k_conv3x3_bpp_bf16<LG_, LG_, NT_, true><<<gridb, 512, 0, st>>>(a);       \
+        else k_conv3x3_bpp_bf16<LG_, LG_, NT_, false><<<gridb, 512, 0, st>>>(a);             \
+    }
+        if (lg == 4 && nt4) VA_LAUNCH_BPP(4, 4)
+        else if (lg == 4) VA_LAUNCH_BPP(4, 2)
+        else if (lg == 3 && nt4) VA_LAUNCH_BPP(3, 4)
+        else if (lg == 3) VA_LAUNCH_BPP(3, 2)
+        else if (nt4) VA_LAUNCH_BPP(2, 4)
+        else VA_LAUNCH_BPP(2, 2)
+#undef VA_LAUNCH_BPP
+        VA_LAUNCH_CHECK();
+        return VA_OK;
+    }
     const long grid64 = (long)(L.cout / 64) * a.tiles_x * a.tiles_y * tiles_b;
     const int ksteps = 3 * a.taps_x * (a.Cin / 64);
-    const bool autosel = variant == 0 || variant >= 3;  // (the brick variants fall through to the automatic choice)
+    const bool autosel = variant == 0 || variant >= 5;  // (variants 5 / 6 fall through to the automatic choice where they do not apply)
     const bool ring = autosel ? (grid64 < VA_RING_MAXGRID && ksteps >= VA_RING) : (variant == 2 && ksteps >= VA_RING);
     const bool wide = autosel && !ring && L.cout % 128 == 0;
     a.tiles_n = L.cout / (wide ? 128 : 64);
@@ -2073,7 +2053,7 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
     if (m->dtype == VA_DTYPE_BF16) {
         // bf16 activations live in the same two ping-pong buffers (half their size is used)
         int first = 0;
-        if (m->conv[0].xcol && m->bf16_first == 1 && m->wp_f1 != nullptr) {
+        if (m->conv[0].xcol && m->bf16_first == 1 && m->wp_f1 != nullptr && ((uintptr_t)x & 15) == 0) {  // (it loads four pixels at a time)
             // the first layer straight from the NCHW input (no staged 64-channel copy of the input)
             Conv1Args c1{x, m->wp_f1, m->conv[0].bias, (__bf16*)act[0], m->in_mean, m->in_std, B, m->c_in, m->f1_cp, m->f1_krow};
             const unsigned g1 = (unsigned)(B * (224 / 16) * (224 / 16));
@@ -2121,7 +2101,7 @@ extern "C" int va_vgg16_set_option(va_vgg16* m, int option, int value)
     VA_CHECK_ARG(m != nullptr, "va_vgg16_set_option: model is NULL");
     switch (option) {
         case VA_OPT_BF16_VARIANT:
-            VA_CHECK_ARG(value >= 0 && value <= 5, "va_vgg16_set_option: VA_OPT_BF16_VARIANT must be in [0,5]");
+            VA_CHECK_ARG((value >= 0 && value <= 2) || value == 5 || value == 6, "va_vgg16_set_option: VA_OPT_BF16_VARIANT must be 0, 1, 2, 5 or 6");
             m->bf16_variant = value;
             return VA_OK;
         case VA_OPT_BF16_FIRST_LAYER:

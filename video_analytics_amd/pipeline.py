@@ -54,11 +54,13 @@ class TwoStreamPipeline(object):
         self.flow_streams = max(1, int(flow_streams))
         self.depth = max(1, int(depth))
         self._cnn = torch.cuda.Stream(device=dev, priority=0)
+        self._cnn2 = torch.cuda.Stream(device=dev, priority=0)  # precomputed flow volumes: the temporal CNN beside the spatial one
         self._n = 0
         self._flow = [None] * self.depth      # per slot: flow [pairs,2,H,W] written by the TV-L1 streams
         self._stack = [None] * self.depth     # per slot: flow volume read by the temporal CNN
         self._flow_read = [None] * self.depth  # per slot: event "the flow buffer has been quantised" (it may be overwritten)
         self._handed_out = []                 # output tensors allocated on the CNN stream since the last wait()
+        self._t_done = None                   # event behind the temporal model's last forward (it owns ONE workspace)
 
     def flow_volume(self, gray):
         """gray u8/f32 ``[B, L+1, 224, 224]`` -> flow volume f32 ``[B, 2L, 224, 224]`` (ordered on the current stream)."""
@@ -108,10 +110,24 @@ class TwoStreamPipeline(object):
                 done = torch.cuda.Event()
                 done.record(self._cnn)
                 self._flow_read[k] = done
+                if self._t_done is not None:
+                    self._cnn.wait_event(self._t_done)
+                _, desc_t, logits_t = self.temporal.forward(stack)
+                self._t_done = torch.cuda.Event()
+                self._t_done.record(self._cnn)
             else:
-                flow_stack.record_stream(self._cnn)
-                stack = flow_stack
-            _, desc_t, logits_t = self.temporal.forward(stack)
+                # no TV-L1 to share the GPU with: the two CNNs (independent models, workspaces of their own) run on two
+                # streams, so that the half-empty last round of one layer's workgroups overlaps the other model's layer
+                # (measured on the bf16 stack: 2.63 -> 2.53 ms per batch)
+                self._cnn2.wait_event(ready)
+                if self._t_done is not None:
+                    self._cnn2.wait_event(self._t_done)
+                with torch.cuda.stream(self._cnn2):
+                    flow_stack.record_stream(self._cnn2)
+                    _, desc_t, logits_t = self.temporal.forward(flow_stack)
+                    self._t_done = torch.cuda.Event()
+                    self._t_done.record(self._cnn2)
+                self._cnn.wait_stream(self._cnn2)
             finished = torch.cuda.Event()
             finished.record(self._cnn)
         out = dict(logits_s=logits_s, logits_t=logits_t, desc_s=desc_s, desc_t=desc_t)
@@ -134,6 +150,7 @@ class TwoStreamPipeline(object):
         return out
 
     def close(self):
+        self._cnn2.synchronize()
         self._cnn.synchronize()
         self.spatial.close()
         self.temporal.close()
