@@ -97,6 +97,29 @@ def test_u8_input_normalisation_matches_oracle(weights3):
     m.close()
 
 
+@pytest.mark.parametrize("c_in", [1, 2, 5, 8, 21])
+def test_bf16_fused_first_layer_other_channel_counts(weights3, c_in):
+    # the fused first layer pads the channels of its LDS patch to a multiple of 4 and a kernel row to 16-element blocks:
+    # 1 -> 4 / 16, 5 -> 8 / 32, 21 -> 24 / 80 (the largest it accepts); against the staged path (input conversion + three K
+    # steps), which is bit-equal when no channel is padded (8) and within bf16 noise otherwise
+    from video_analytics_amd import _ffi, vgg
+    w = {k: [t.clone() for t in v] for k, v in weights3.items()}
+    g = torch.Generator().manual_seed(100 + c_in)  # (distinct weights per channel and tap: a permuted K order would show)
+    w["conv_w"][0] = torch.randn(64, c_in, 3, 3, generator=g) * float(w["conv_w"][0].std()) * (3.0 / c_in) ** 0.5
+    x = _inputs(2, c_in, seed=40 + c_in).cuda()
+    outs = []
+    for first in (1, 0):
+        m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256, dtype="bf16")
+        m.set_option(_ffi.VA_OPT_BF16_FIRST_LAYER, first)
+        feat, _, logits = m.forward(x, want_feat=True)
+        outs.append((feat.cpu(), logits.cpu()))
+        m.close()
+    ls = float(outs[1][1].abs().max())
+    assert float((outs[0][1] - outs[1][1]).abs().max()) / ls < 1e-2
+    if c_in % 4 == 0:
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_bf16_u8_input_goes_through_the_fused_first_layer(weights3):
     # the bf16 first layer converts u8 frames itself (ToTensor + Normalize in the kernel): same scores as the bf16 model fed
     # the normalised floats, up to bf16 roundings of inputs that differ in their last float bit
