@@ -1133,11 +1133,14 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
         for (; s < s_a; ++s) step(s, std::false_type{});
 #if VA_STREAM_UNROLL2
         // two steady steps per loop trip: the rows a level hands on and keeps (c_* -> P[t], n -> U[t]) change registers
-        // by renaming between the two copies instead of by v_mov (5 per level and step otherwise)
-        for (; s + 1 < s_b; s += 2) {
-            step(s, std::true_type{});
-            step(s + 1, std::true_type{});
-        }
+        // by renaming between the two copies instead of by v_mov (5 per level and step otherwise).  Not in the one-wave
+        // form: with ten levels in one wave's 256 registers the second copy spills (19-21 registers; 1280x720: 62 instead
+        // of 114 pairs/s)
+        if constexpr (NWV > 1)
+            for (; s + 1 < s_b; s += 2) {
+                step(s, std::true_type{});
+                step(s + 1, std::true_type{});
+            }
 #endif
         for (; s < s_b; ++s) step(s, std::true_type{});
         for (; s < nsteps; ++s) step(s, std::false_type{});
