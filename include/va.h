@@ -116,6 +116,8 @@ int va_vgg16_set_option(va_vgg16* model, int option, int value);
  * x: f32 (x_is_u8 = 0) or u8 (x_is_u8 = 1) [batch][c_in][224][224] NCHW.
  * feat: f32 [batch][512][7][7] NCHW or NULL; desc: f32 [batch][desc_dim] (post-ReLU output of
  * classifier index 8) or NULL; logits: f32 [batch][n_classes] (no softmax) or NULL.
+ * VA_DTYPE_BF16 models: batch <= 334 (a layer's activations are addressed with 32-bit byte offsets; VA_ERR_INVALID
+ * beyond that: split the batch).
  */
 int va_vgg16_forward(va_vgg16* model, const void* x, int x_is_u8, int batch,
                      void* feat, void* desc, void* logits,

@@ -120,6 +120,20 @@ def test_bf16_fused_first_layer_other_channel_counts(weights3, c_in):
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_bf16_batch_beyond_32bit_buffer_offsets_is_rejected(weights3):
+    # the bf16 staging addresses a layer's activations with 32-bit byte offsets: 336 images x 224 x 224 x 64 bf16 channels
+    # are 2.16 GB -- refused with a message (the fp32 path has no such limit); 330 images (2.12 GB < 2^31) still run
+    from video_analytics_amd import vgg
+    w = weights3
+    m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256, dtype="bf16")
+    x = torch.zeros(336, 3, 224, 224, dtype=torch.float32, device="cuda")
+    with pytest.raises(ValueError, match="split the batch"):
+        m.forward(x)
+    _, _, logits = m.forward(x[:330])
+    assert bool(torch.isfinite(logits).all()) and torch.equal(logits[0], logits[329])
+    m.close()
+
+
 def test_bf16_u8_input_goes_through_the_fused_first_layer(weights3):
     # the bf16 first layer converts u8 frames itself (ToTensor + Normalize in the kernel): same scores as the bf16 model fed
     # the normalised floats, up to bf16 roundings of inputs that differ in their last float bit

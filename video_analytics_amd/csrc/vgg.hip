@@ -1700,6 +1700,10 @@ int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const
     a.H = a.W = L.hw;
     a.Cin = L.cin_pad;
     a.Cout = L.cout;
+    // the staging addresses a layer's activations with 32-bit buffer offsets (bytes)
+    VA_CHECK_ARG(((long)B * L.hw * L.hw + 2L * (L.hw + 1)) * L.cin_pad * 2 < 2147483647L,
+                 "va_vgg16_forward (bf16): batch %d x %dx%dx%d activations exceed 2 GiB of 32-bit buffer offsets: split the batch", B,
+                 L.hw, L.hw, L.cin_pad);
     pick_brick(L.hw, L.hw, B, a.lgTW, a.lgTH, a.TB);
     a.tiles_x = va_cdiv(L.hw, 1 << a.lgTW);
     a.tiles_y = va_cdiv(L.hw, 1 << a.lgTH);
