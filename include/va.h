@@ -94,10 +94,12 @@ size_t va_vgg16_workspace_bytes(const va_vgg16* model, int batch);
  *   VA_OPT_BF16_VARIANT     0 (default) kernel, tile and staging scheme chosen per layer (measured); 1 = 64-channel
  *                           tiles with one LDS buffer on every layer; 2 = the LDS-DMA ring on every layer; 5 = the
  *                           two-group kernel (k_conv3x3_pp_bf16) on every layer with >= 128 output channels and >= 28x28
- *                           pixels (the default uses it on the 28x28 layers); 0, 1, 2 and 5 add the same products in the
+ *                           pixels (the default uses it on the 28x28 layers); 0, 1, 2, 5 and 7 add the same products in the
  *                           same order and agree bit for bit.  6 = the two-group kernel on halo bricks
  *                           (k_conv3x3_bpp_bf16; chunk-major K order: another fp32 summation order, so within bf16 noise
- *                           of the others; measured no faster).  (3 and 4, round 2's first halo-brick kernel, are gone.)
+ *                           of the others; measured no faster).  7 = the weights-resident kernel (k_conv3x3_ws_bf16) on
+ *                           both layers with 64 input channels (the default uses it on conv1_2 only); bit-equal to 0, 1, 2, 5.
+ *                           (3 and 4, round 2's first halo-brick kernel, are gone.)
  *   VA_OPT_BF16_FIRST_LAYER 1 (default) the first layer reads the NCHW input itself (k_conv1_fused_bf16); 0 = the input is
  *                           first staged as a 64-channel NHWC tensor and convolved in three K steps (the round-1 path;
  *                           another fp32 summation order: bf16-level agreement).  Independent of VA_OPT_BF16_VARIANT

@@ -250,7 +250,7 @@ def test_bf16_stream_against_its_own_restatement_and_across_staging_schemes(weig
     feat_r, desc_r, log_r = vgg_oracle.forward_bf16(x, w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"])
     outs = []
     from video_analytics_amd import _ffi
-    for variant in (0, 1, 2, 5):  # (5: the two-group kernel -- the same K order per accumulator, so bit-equal too)
+    for variant in (0, 1, 2, 5, 7):  # (5: the two-group kernel, 7: the weights-resident kernel -- the same K order per accumulator, so bit-equal too)
         m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256, dtype="bf16")
         m.set_option(_ffi.VA_OPT_BF16_VARIANT, variant)
         feat, desc, logits = m.forward(x.cuda(), want_feat=True)

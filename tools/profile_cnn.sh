@@ -2,6 +2,7 @@
 # MFMA utilisation of the conv kernels (profiles/rNN/conv_mfma_util.txt): counter pass + kernel trace of the CNN-only
 # workload, fp32 and bf16.   bash tools/profile_cnn.sh gpurun_out/r02m
 set -e
+export ONE_STREAM=1  # the two models one after the other: per-kernel durations are their own
 P=$1
 mkdir -p $P
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null

@@ -5,6 +5,7 @@ P=$1
 V=$2
 mkdir -p $P
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+export ONE_STREAM=1  # kernels of the two models do not overlap: per-kernel durations are their own
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace_v$V -- python3 tools/bench_cnn_only.py bf16 $V > $P/trace_v$V.log 2>&1
 python3 - $P/trace_v$V <<'PY'
 import csv, glob, sys, collections

@@ -1267,6 +1267,162 @@ __global__ void __launch_bounds__(512) k_conv3x3_bpp_bf16(ConvArgsBf a)
     conv3x3_bpp_body<LGTW, LGTH, NT, POOL>(a);
 }
 
+// ---------------------------------------------------------------- bf16 conv3x3 with 64 input channels: weights resident ----
+//
+// conv1_2 (64 -> 64 at 224 x 224) and conv2_1 (64 -> 128 at 112 x 112) have K = 576: nine tap-major steps of the kernels
+// above, each staging (128 pixels + 64 or 128 channels) x 128 B for 8 or 16 MFMAs per wave -- 2.7 GB through the CUs'
+// vector-memory path for conv1_2 at batch 32, which is what its 162 us are (the measured 27-29 B/clk per CU).
+// k_conv3x3_ws_bf16 stages the WEIGHTS once per workgroup -- 64 output channels x 576 x 2 B = 72 KB stay in LDS -- and
+// the workgroup walks over 16 x 16-pixel bricks: per brick it stages the 18 x 18 halo patch (41 KB, double-buffered: the
+// next brick's patch lands during this brick's 576 MFMAs) and forms the nine taps by shifting the fragment's row index.
+// No barrier inside a brick: four waves, one per SIMD, each 64 pixels x 64 channels, run their 144 MFMAs on operands that
+// are all in LDS; two barriers per brick (patch swap; the epilogue's staging tiles reuse the patch just consumed).
+//   * 72 B staged per MFMA instead of 768;
+//   * one 64-channel chunk, so chunk-major = tap-major: the same products in the same order per accumulator as
+//     k_conv3x3_mfma_bf16 -- bit-equal results (tested);
+//   * weight rows are padded to 1168 B (conflict-free 16-lane fragment reads); patch rows are 128 B with a source-side
+//     swizzle keyed on the patch COORDINATES: chunk c of patch pixel (yy, xx) sits at slot c ^ (((xx >> 1) + 4 yy) & 7).
+//     A fragment's 16-lane read group holds the pixels x in {0,1,6,7,10,11,12,13} + const, y in {0,1} + const of the
+//     brick order; their bank positions 2 slot + (xx & 1) = (xx + 8 yy) mod 16 are then all different, for every tap
+//     (keyed on the row index (R >> 1) & 7, two of the sixteen collided: a third of the LDS cycles were conflict cycles);
+//   * workgroup w serves channel half w % (Cout / 64) of the bricks w / NH, w / NH + G / NH, ...: G = the CU count
+//     (158 KB of LDS: one workgroup per CU).
+struct ConvArgsWs {
+    ConvArgsBf c;      // lgTW = lgTH = 4, TB = 1, tiles_x = W / 16, tiles_y = H / 16; Cin = 64
+    int n_bricks;      // B * tiles_y * tiles_x
+};
+
+template <bool POOL>
+__device__ __forceinline__ void conv3x3_ws_body(const ConvArgsWs& aw)
+{
+    const ConvArgsBf& a = aw.c;
+    constexpr int PW = 18, NR = 18 * 18, A_ROWS = 328, A_BYTES = A_ROWS * 128;  // 41 pieces of 8 rows
+    constexpr int WSTRIDE = 1168, W_BYTES = 64 * WSTRIDE;
+    constexpr int NPIECE = A_ROWS / 8, PPW = (NPIECE + 3) / 4;                  // pieces per wave (11: the last wave has 8)
+    __shared__ __attribute__((aligned(1024))) char smem[2 * A_BYTES + W_BYTES];
+    char* const sA = smem;
+    char* const sW = smem + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W;
+    const int NH = a.Cout / 64, nh = blockIdx.x % NH, nb = nh * 64;
+    const int first = blockIdx.x / NH, stride = gridDim.x / NH;
+
+    // the weights of this channel half: [64][576] bf16 -> LDS rows of WSTRIDE bytes (once)
+    {
+        const uint4* src = (const uint4*)(a.wp + (size_t)nb * 576);
+        for (int i = tid; i < 64 * 72; i += 256) {
+            const int n = i / 72, c = i - n * 72;
+            *(uint4*)(sW + n * WSTRIDE + 16 * c) = src[i];
+        }
+    }
+
+    // loader role: row (lane >> 3) of an 8-row piece, slot (lane & 7); per piece the patch pixel (yy, xx) and its offset
+    // relative to the brick's first pixel
+    const __amdgpu_buffer_rsrc_t rs_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.in), 0, (int)((long)a.B * H * W * 64 * 2), 0x00020000);
+    const int lrow = lane >> 3, lslot = lane & 7;
+    int rel[PPW], pyx[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int R = (wave * PPW + i) * 8 + lrow;
+        const int yy = R / PW, xx = R - yy * PW;
+        rel[i] = (((yy - 1) * W + (xx - 1)) * 64 + 8 * (lslot ^ (((xx >> 1) + 4 * yy) & 7))) * 2;
+        pyx[i] = R < NR ? (yy << 8) | xx : -1;
+    }
+    auto stage_a = [&](int brick, int buf) {
+        const int tx = brick % a.tiles_x, r1 = brick / a.tiles_x, ty = r1 % a.tiles_y, b = r1 / a.tiles_y;
+        const int X0 = tx << 4, Y0 = ty << 4;
+        const int base = (((b * H + Y0) * W + X0) * 64) * 2;
+        static_for<PPW>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if ((wave * PPW + i) < NPIECE) {  // (wave-uniform)
+                const int y = Y0 + (pyx[i] >> 8) - 1, x = X0 + (pyx[i] & 255) - 1;
+                const bool ok = pyx[i] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(sA + buf * A_BYTES + (wave * PPW + i) * 1024), 16,
+                                                         ok ? base + rel[i] : 0x7fffffff, 0, 0, 0);
+            }
+        });
+    };
+
+    // fragment role
+    const int r31 = lane & 31, hh = lane >> 5;
+    int idx0[2], px0[2], py0[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int xl, yl, bl;
+        brick_coords(64 * wave + 32 * mt + r31, 4, 4, xl, yl, bl);
+        px0[mt] = xl + 1;
+        py0[mt] = yl + 1;
+        idx0[mt] = py0[mt] * PW + px0[mt];
+    }
+    const char* const wfrag = sW + r31 * WSTRIDE + hh * 16;
+
+    if (first < aw.n_bricks) stage_a(first, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int buf = 0;
+    for (int brick = first; brick < aw.n_bricks; brick += stride) {
+        if (brick + stride < aw.n_bricks) stage_a(brick + stride, buf ^ 1);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+        const char* const pA = sA + buf * A_BYTES;
+        // 36 k-steps (9 taps x 4 blocks of 16 channels), the fragments of step i + 2 fetched before the MFMAs of step i
+        // are issued (one wave per SIMD: nothing else hides the LDS latency; one step ahead measured 134 us, none 148)
+        bf16x8 fa[3][2], fb[3][2];
+        auto fetch = [&](int i, int slot) __attribute__((always_inline)) {
+            const int tap = i >> 2, ks = i & 3;
+            const int toff = (tap / 3 - 1) * PW + (tap % 3) - 1;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int row = idx0[mt] + toff;
+                const int sw = (((px0[mt] + (tap % 3) - 1) >> 1) + 4 * (py0[mt] + tap / 3 - 1)) & 7;
+                fa[slot][mt] = *reinterpret_cast<const bf16x8*>(pA + row * 128 + (((2 * ks + hh) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                fb[slot][nt] = *reinterpret_cast<const bf16x8*>(wfrag + nt * 32 * WSTRIDE + (tap * 64 + ks * 16) * 2);
+        };
+        fetch(0, 0);
+        fetch(1, 1);
+#pragma unroll
+        for (int i = 0; i < 36; ++i) {
+            if (i + 2 < 36) fetch(i + 2, (i + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = kWeightsFirst<POOL> ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i % 3][nt], fa[i % 3][mt], acc[mt][nt], 0, 0, 0)
+                                                      : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % 3][mt], fb[i % 3][nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave has read this brick's patch: it becomes the staging tiles
+        {
+            const int tx = brick % a.tiles_x, r1 = brick / a.tiles_x, ty = r1 % a.tiles_y, b = r1 / a.tiles_y;
+            epilogue_lines_bf16<2, POOL>(acc, (__bf16*)(sA + buf * A_BYTES) + wave * 64 * 64, a, 64 * wave, nb, tx << 4, ty << 4, b, lane);
+        }
+        // the next patch has landed (and this wave's staging reads are done) before anyone stages into this buffer again
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        buf ^= 1;
+    }
+}
+
+template <bool POOL>
+__global__ void __launch_bounds__(256) k_conv3x3_ws_bf16(ConvArgsWs a)
+{
+    conv3x3_ws_body<POOL>(a);
+}
+
 // ---------------------------------------------------------------- fp32 conv3x3, LDS-DMA staging ---------
 //
 // The bf16 kernel's structure (LDS-DMA with source-side swizzle, one 32 KB buffer, four workgroups per CU, or
@@ -1596,6 +1752,9 @@ constexpr long VA_WIDE_MIN = 512;           // register-staged fp32 kernel: 128-
 constexpr int VA_RING = 3;                  // depth of the LDS-DMA ring (two workgroups per CU)
 constexpr long VA_RING_MAXGRID = 1024;      // bf16: ring + 64-channel tiles below this many workgroups (the 14x14 layers)
 constexpr long VA_RING_MAXGRID_F32 = 1024;  // fp32: the same threshold (0 and 4096 measured 2-4 % slower)
+#ifndef VA_WS_DEFAULT
+#define VA_WS_DEFAULT 1     // bf16: the weights-resident kernel on the layers with 64 input channels
+#endif
 #ifndef VA_BPP_DEFAULT
 #define VA_BPP_DEFAULT 0    // bf16: 1 = the two-group halo-brick kernel wherever it applies (set after measurement)
 #endif
@@ -1687,7 +1846,8 @@ int launch_conv(const ConvLayer& L, const float* zeros, const float* in, float* 
     return launch_conv_ex(L.hw, L.cin_pad, L.cout, L.wp, L.bias, in, out, nullptr, 0, L.pool, B, zeros, f32_conv, st);
 }
 
-int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const __bf16* in, void* out, bool out_f32, int B, hipStream_t st)
+int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const __bf16* in, void* out, bool out_f32, int B, int n_cu,
+                     hipStream_t st)
 {
     ConvArgsBf a{};
     a.in = in;
@@ -1742,6 +1902,24 @@ int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const
         VA_LAUNCH_CHECK();
         return VA_OK;
     }
+    // The weights-resident kernel (k_conv3x3_ws_bf16) on the layers with 64 input channels: variant 7 forces it (conv1_2
+    // and conv2_1), the default uses it where it measured faster: 64 output channels (conv1_2: 135 against 162 us; conv2_1
+    // with its two channel halves: 84 against 80).  Same products in the same order as the tap-major kernel: bit-equal
+    if ((variant == 7 || (variant == 0 && VA_WS_DEFAULT && L.cout == 64)) && !L.xcol && !out_f32 && a.Cin == 64 && L.cout % 64 == 0 &&
+        L.cout <= 256 && L.hw % 16 == 0 && n_cu >= L.cout / 64) {
+        ConvArgsWs w{};
+        w.c = a;
+        w.c.lgTW = w.c.lgTH = 4;
+        w.c.TB = 1;
+        w.c.tiles_x = w.c.tiles_y = L.hw / 16;
+        w.n_bricks = B * w.c.tiles_x * w.c.tiles_y;
+        const int nh = L.cout / 64;
+        const unsigned gridw = (unsigned)((n_cu / nh) * nh);  // one workgroup per CU (158 KB of LDS), whole channel-half groups
+        if (L.pool) k_conv3x3_ws_bf16<true><<<gridw, 256, 0, st>>>(w);
+        else k_conv3x3_ws_bf16<false><<<gridw, 256, 0, st>>>(w);
+        VA_LAUNCH_CHECK();
+        return VA_OK;
+    }
     // variant 6: the two-group kernel on halo bricks (k_conv3x3_bpp_bf16) on the layers with >= 128 output channels and
     // 28 x 28 pixels or more (16 x 16 bricks; 8 x 8 of four images; 4 x 4 of sixteen)
     if ((variant == 6 || (variant == 0 && VA_BPP_DEFAULT)) && !L.xcol && !out_f32 && a.Cin % 32 == 0 && L.cout % 128 == 0 &&
@@ -1770,7 +1948,7 @@ int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const
     }
     const long grid64 = (long)(L.cout / 64) * a.tiles_x * a.tiles_y * tiles_b;
     const int ksteps = 3 * a.taps_x * (a.Cin / 64);
-    const bool autosel = variant == 0 || variant >= 5;  // (variants 5 / 6 fall through to the automatic choice where they do not apply)
+    const bool autosel = variant == 0 || variant >= 5;  // (variants 5 .. 7 fall through to the automatic choice where they do not apply)
     const bool ring = autosel ? (grid64 < VA_RING_MAXGRID && ksteps >= VA_RING) : (variant == 2 && ksteps >= VA_RING);
     const bool wide = autosel && !ring && L.cout % 128 == 0;
     a.tiles_n = L.cout / (wide ? 128 : 64);
@@ -2076,7 +2254,7 @@ extern "C" int va_vgg16_forward(va_vgg16* m, const void* x, int x_is_u8, int bat
             k_nchw_to_nhwc_pad<float, __bf16><<<pgrid, 256, 0, st>>>((const float*)x, (__bf16*)act[1], B, m->c_in, HW0, m->c_in_pad, nullptr, nullptr);
         VA_LAUNCH_CHECK();
         for (int i = first; i < 13; ++i) {
-            if (int rc = launch_conv_bf16(m->conv[i], m->zeros, m->bf16_variant, (const __bf16*)act[cur], act[cur ^ 1], i == 12, B, st)) return rc;
+            if (int rc = launch_conv_bf16(m->conv[i], m->zeros, m->bf16_variant, (const __bf16*)act[cur], act[cur ^ 1], i == 12, B, m->ctx->n_cu, st)) return rc;
             cur ^= 1;
         }
     } else {
@@ -2105,7 +2283,7 @@ extern "C" int va_vgg16_set_option(va_vgg16* m, int option, int value)
     VA_CHECK_ARG(m != nullptr, "va_vgg16_set_option: model is NULL");
     switch (option) {
         case VA_OPT_BF16_VARIANT:
-            VA_CHECK_ARG((value >= 0 && value <= 2) || value == 5 || value == 6, "va_vgg16_set_option: VA_OPT_BF16_VARIANT must be 0, 1, 2, 5 or 6");
+            VA_CHECK_ARG((value >= 0 && value <= 2) || (value >= 5 && value <= 7), "va_vgg16_set_option: VA_OPT_BF16_VARIANT must be 0, 1, 2, 5, 6 or 7");
             m->bf16_variant = value;
             return VA_OK;
         case VA_OPT_BF16_FIRST_LAYER:
