@@ -175,7 +175,9 @@ typedef struct va_tvl1_params {
                           (0 = full resolution) iterates with the row pipeline, every other level on the register tiles */
     int stream_waves;  /* 0 (default): two-wave pipeline (16 iterations per pass) where a level has at most two strips,
                           one-wave (10 per pass) elsewhere; 1: one-wave pipeline everywhere; 3: where the two-wave
-                          pipeline would run, ONE wave with all 16 levels and a whole SIMD's registers (measured slower) */
+                          pipeline would run, ONE wave with all 16 levels and a whole SIMD's registers (measured slower);
+                          4: the two-wave pipeline in 512-thread workgroups of FOUR jobs each, the two waves of a job on the
+                          same SIMD (k_iter_stream4; measured 2 % slower) */
     int stream_chunks; /* 0 (default): rows cut into as many chunks as fill the GPU; n > 0: n chunks (capped at h/32) */
     int stream_slots;  /* 0 (default): target number of strip x chunk x pair jobs per call (640 two-wave / 1024 one-wave) */
     /* The persistent row pipeline (k_iter_rows: all `iters` iterations of a warp step in one launch, one workgroup per

@@ -106,6 +106,19 @@ def test_streaming_kernel_one_deep_wave_bit_exact(oracle_tvl1, H, W, nch):
         assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("H,W,nch,nseq", [(224, 224, 0, 1), (224, 224, 2, 3), (100, 64, 3, 1), (129, 225, 2, 2), (57, 131, 1, 5), (179, 179, 2, 1),
+                                          (114, 114, 3, 2), (40, 40, 1, 1)])
+def test_four_jobs_per_workgroup_bit_exact(oracle_tvl1, H, W, nch, nseq):
+    # stream_waves = 4: k_iter_stream4 -- 512-thread workgroups run four (strip, chunk, pair) jobs each, the two waves of a job on
+    # the same SIMD; job counts that are not multiples of four (padding jobs), chunks of different lengths in one workgroup
+    # (padded step counts), several pairs per workgroup
+    gray = _frames(nseq, 3, H, W, seed=2 * H + W + nseq)
+    for iters, warps, nscales in ((10, 1, 1), (37, 2, 3)):
+        ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=warps, nscales=nscales, tile_mask=1 << 8,
+                             stream_chunks=nch, stream_waves=4)
+        assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
 @pytest.mark.parametrize("H,W,nch,slots", [(224, 224, 0, 0), (224, 224, 2, 3), (100, 64, 3, 2), (129, 225, 2, 7), (57, 131, 1, 1), (179, 179, 2, 0),
                                            (114, 114, 3, 5)])
 def test_queued_row_pipeline_bit_exact(oracle_tvl1, H, W, nch, slots):

@@ -337,6 +337,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef VA_STREAM_QUEUE_DEFAULT
 #define VA_STREAM_QUEUE_DEFAULT 0  // 1: k_iter_stream_q (all passes of a warp step in one launch) wherever it applies
 #endif
+#ifndef VA_STREAM4_DEFAULT
+#define VA_STREAM4_DEFAULT 0  // 1: four jobs per 512-thread workgroup (k_iter_stream4) wherever the two-wave pipeline runs
+#endif
 #ifndef VA_STREAM_UNROLL2
 #define VA_STREAM_UNROLL2 1  // measured on the 224^2 level: 9.8 -> 9.3 ms per warp step of 320 pairs
 #endif
@@ -853,9 +856,15 @@ struct StreamArgs {
 // workgroup barrier per step keeps them a step apart.
 // PPL pixels per lane: a strip is 64 * PPL columns wide (2: 128, the default; 3: 192, so that a 129..192-column level is
 // ONE well-filled strip without any x halo -- a tested option that measured no faster, see stream_ppl()).
-template <int PPL, int KH, int NWV, bool FAST>
+// SUBS = 4 (k_iter_stream4): a 512-thread workgroup runs FOUR jobs, job `sub` on the waves sub (first wave) and sub + 4
+// (second wave) -- the dispatcher puts waves w and w + 4 of a workgroup on the same SIMD, so the two waves of a pipeline
+// share one: while one of them waits for the other, the other has the SIMD to itself.  All eight waves meet at every
+// barrier, so every job of the workgroup runs `steps_pad` steps (a job with fewer only joins the barrier); `active` =
+// false: a padding job.
+template <int PPL, int KH, int NWV, bool FAST, int SUBS = 1>
 __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, const int job, const int K,
-                                           const float* __restrict__ sin_all, float* __restrict__ sout_all)
+                                           const float* __restrict__ sin_all, float* __restrict__ sout_all, const int sub = 0,
+                                           const int role = -1, const bool active = true, const int steps_pad = 0)
 {
     typedef Row<PPL> R;
     constexpr int NP = R::NP, NT = R::NT, SW = 64 * PPL;
@@ -863,15 +872,19 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
     // wave writes row s - 1 at the start of step s (after the barrier), the oldest row read in step s is
     // s - (KH + 1) - (KH - 1) = s - 2 KH.
     constexpr int NRING = NWV == 1 ? KH - 1 : NWV * KH;
-    __shared__ f2 ringP[NRING][kNF_RO][NP][64];
-    __shared__ float ringT[NRING][kNF_RO][NT ? 64 : 1];
-    __shared__ f2 ifaceP[NWV > 1 ? NWV - 1 : 1][2][kNF_STATE][NP][64];
-    __shared__ float ifaceT[NWV > 1 ? NWV - 1 : 1][2][kNF_STATE][NT ? 64 : 1];
+    __shared__ f2 ringP_[SUBS][NRING][kNF_RO][NP][64];
+    __shared__ float ringT_[SUBS][NRING][kNF_RO][NT ? 64 : 1];
+    __shared__ f2 ifaceP_[SUBS][NWV > 1 ? NWV - 1 : 1][2][kNF_STATE][NP][64];
+    __shared__ float ifaceT_[SUBS][NWV > 1 ? NWV - 1 : 1][2][kNF_STATE][NT ? 64 : 1];
+    auto& ringP = ringP_[sub];
+    auto& ringT = ringT_[sub];
+    auto& ifaceP = ifaceP_[sub];
+    auto& ifaceT = ifaceT_[sub];
 
     const int sx = job % a.nsx, ch = job / a.nsx;
     const int w = a.w, h = a.h, pitch = a.pitch;
     const int lane = threadIdx.x & 63;
-    const int wv = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wv = NWV == 1 ? 0 : role >= 0 ? role : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ox = sx * (SW - 2 * a.HX);
     const int vx0 = ox + (sx > 0 ? a.HX : 0), vx1 = (sx == a.nsx - 1) ? pitch : ox + SW - a.HX;
     const int x0 = ox + PPL * lane;  // (the pitch, the halo and so every strip origin are multiples of PPL)
@@ -943,7 +956,7 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
     auto st = [&](const R& v, int f, int y) { row_store<PPL>(v, rs_out, loff, f * planeb + y * pitchb); };
 
     // level K-1 (in the last wave) emits row b0-1 when row b0 (or the dummy row h) comes in; every wave boundary adds a step
-    const int nsteps = b0 - ys + K + (NWV - 1);
+    const int nsteps = active ? b0 - ys + K + (NWV - 1) : 0;
 
     auto run = [&](auto wave_tag) __attribute__((always_inline)) {
         constexpr int W = decltype(wave_tag)::value;
@@ -1128,7 +1141,7 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
         // steady state of this wave: steps [s_a, s_b) (all its KH levels inside their row windows, below the last row)
         int s_a = d_max(KH - 1, a0 - K + G0 + 2 * KH - 2) - ys + LAG;
         int s_b = d_min(nsteps, d_min(h - 1, b0 + K - G0 - 1) - ys + LAG + 1);
-        if (K < G0 + KH || s_a > s_b) s_a = s_b = 0;
+        if (K < G0 + KH || s_a > s_b || !active) s_a = s_b = 0;
         int s = 0;
         for (; s < s_a; ++s) step(s, std::false_type{});
 #if VA_STREAM_UNROLL2
@@ -1144,6 +1157,8 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
 #endif
         for (; s < s_b; ++s) step(s, std::true_type{});
         for (; s < nsteps; ++s) step(s, std::false_type{});
+        if constexpr (SUBS > 1)  // the other jobs of the workgroup may have more steps: join their barriers
+            for (; s < steps_pad; ++s) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     if constexpr (NWV == 1) {
         run(std::integral_constant<int, 0>{});
@@ -1166,6 +1181,27 @@ __global__ void __launch_bounds__(NWV * 64)
         if (a.rev) lid = nb - 1 - lid;
     }
     stream_job<PPL, KH, NWV, FAST>(a, a.pair0 + (int)(lid / gridDim.x), (int)(lid % gridDim.x), a.K, a.sin, a.sout);
+}
+
+// Four jobs per 512-thread workgroup (see stream_job, SUBS): gridDim.x workgroups cover a.njobs4 = 4 gridDim.x (>= jobs x
+// pairs) flattened jobs; the ones beyond the call's jobs are padding.
+template <bool FAST>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_iter_stream4(StreamArgs a, int jobs_per_pair, int njobs)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sub = wave & 3, role = wave >> 2;
+    unsigned lid = blockIdx.x;
+    {
+        const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, xcd = lid % 8, kk = lid / 8;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+        if (a.rev) lid = nb - 1 - lid;
+    }
+    const int j = (int)lid * 4 + sub;
+    const bool active = j < njobs;
+    const int jj = active ? j : 0;
+    // every job of the call has at most R + 2 K + 2 steps (rows of a chunk + its K-row halos + the pipeline depth + the wave boundary)
+    const int steps_pad = a.R + 3 * a.K + 2;
+    stream_job<2, 8, 2, FAST, 4>(a, a.pair0 + jj / jobs_per_pair, jj % jobs_per_pair, a.K, a.sin, a.sout, sub, role, active, steps_pad);
 }
 
 // k_iter_stream_q: ALL passes of a warp step in one launch, as a queue of tasks (pass, pair, strip, chunk) that
@@ -1620,6 +1656,7 @@ void launch_iter(const TilePick& tp, const IterArgs& a, int npairs, hipStream_t 
 // ---- k_iter_stream: strips x chunks of a level
 constexpr int kStreamK1 = 10;       // one-wave pipeline: iterations per pass (2 pixels per lane)
 constexpr int kStreamKH2 = 8;       // two-wave pipeline: levels per wave (16 iterations per pass; 2 pixels per lane)
+static_assert(kStreamKH2 == 8, "k_iter_stream4 instantiates stream_job<2, 8, 2>");
 // A level keeps 6 x PPL registers per lane: with 3 pixels per lane the pipelines are shallower (5 levels per wave), so
 // that two waves per SIMD still fit the register file (8 and 6 levels spill, seen at compile time and in the timings)
 constexpr int stream_k1(int ppl) { return ppl == 2 ? kStreamK1 : 5; }
@@ -1852,7 +1889,7 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
                  "va_tvl1: rows_levels must be -1 or a level bit set, rows_cfg in [0,255]");
     VA_CHECK_ARG(p->stream_ppl == 0 || p->stream_ppl == 2 || p->stream_ppl == 3, "va_tvl1: stream_ppl must be 0 (default), 2 or 3");
     VA_CHECK_ARG(p->stream_queue >= 0 && p->stream_queue <= 2, "va_tvl1: stream_queue must be 0 (default), 1 (queued) or 2 (a launch per pass)");
-    VA_CHECK_ARG(p->stream_levels >= -1 && p->stream_levels < (1 << kMaxScales) && (p->stream_waves == 0 || p->stream_waves == 1 || p->stream_waves == 3) &&
+    VA_CHECK_ARG(p->stream_levels >= -1 && p->stream_levels < (1 << kMaxScales) && (p->stream_waves == 0 || p->stream_waves == 1 || p->stream_waves == 3 || p->stream_waves == 4) &&
                      p->stream_chunks >= 0 && p->stream_slots >= 0,
                  "va_tvl1: stream_levels must be -1 or a level bit set, stream_waves 0 or 1, stream_chunks and stream_slots >= 0");
     VA_CHECK_ARG(p->tau / p->theta <= 1000.0f && p->lambda * p->theta <= 1000.0f, "va_tvl1: tau/theta and lambda*theta must be <= 1000");
@@ -2198,6 +2235,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                     cur ^= qn & 1;
                     launches = 1;
                 }
+                const bool four = sp.ppl == 2 && (p->stream_waves == 4 || (p->stream_waves == 0 && VA_STREAM4_DEFAULT));
                 for (int it = queued ? p->iters : 0; it < p->iters;) {
                     const int rem = p->iters - it;
                     const int kh2 = stream_kh2(sp.ppl), k1 = stream_k1(sp.ppl);
@@ -2208,6 +2246,10 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                     sa.rev = VA_REV ? (launches & 1) : 0;
                     if (sp.deep1) {
                         k_iter_stream<2, 16, 1, false><<<grid, 64, 0, st>>>(sa);
+                    } else if (w2 && four) {
+                        const int njobs = (int)(grid.x * grid.y), g4 = va_cdiv(njobs, 4);
+                        if (p->fast_math) k_iter_stream4<true><<<g4, 512, 0, st>>>(sa, (int)grid.x, njobs);
+                        else k_iter_stream4<false><<<g4, 512, 0, st>>>(sa, (int)grid.x, njobs);
                     } else if (w2) {
                         if (p->fast_math) launch_stream<true, true>(sp.ppl, grid, st, sa);
                         else launch_stream<true, false>(sp.ppl, grid, st, sa);
