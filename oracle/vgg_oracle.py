@@ -39,6 +39,18 @@ def features(x, conv_w, conv_b):
     return x
 
 
+def classifier_modules(desc_dim=256, n_classes=101):
+    """The ten modules of the swapped classifier in order (Sheet03/spatialModel.py:136-152), as (type, in, out) records;
+    ``classifier`` below evaluates exactly this list with Dropout as the identity (eval mode).  Pinned to the reference's
+    own ``__swapClassifier__`` run on a stub model: tests/test_reference_fixtures.py."""
+    mods = []
+    for i, (fin, fout) in enumerate([(25088, 4096), (4096, 4096), (4096, desc_dim), (desc_dim, n_classes)]):
+        mods.append({"type": "Linear", "in_features": fin, "out_features": fout, "bias": True})
+        if i < 3:
+            mods += [{"type": "ReLU", "inplace": True}, {"type": "Dropout", "p": 0.5}]
+    return mods
+
+
 def classifier(feat, fc_w, fc_b):
     """feat [B,512,7,7] -> (descriptor [B,D], logits [B,nClasses])  (Sheet03/spatialModel.py:213-218)."""
     op = feat.reshape(feat.size(0), -1)

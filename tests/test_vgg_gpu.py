@@ -32,6 +32,18 @@ def test_copy_first_layer_matches_reference_rule(weights3):
     assert torch.equal(out, ref)
 
 
+def test_copy_first_layer_equals_the_reference_run():
+    """``va_copy_first_layer`` against the output of the reference's own ``TemporalNetwork.__copyFirstLayer__``
+    (Sheet03/temporalModel.py:149-162, executed in the build container by tests/golden/make_reference_fixtures.py on a
+    seeded ``Conv2d(3, 64, 3, padding=1)``): bit-equal."""
+    import os
+    from video_analytics_amd import vgg
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_model_kats.npz"))
+    w_in, w_out = torch.from_numpy(z["copyFirstLayer_w_in"]), torch.from_numpy(z["copyFirstLayer_w_out"])
+    out = vgg.copy_first_layer(w_in.cuda(), 20).cpu()
+    assert out.shape == (64, 20, 3, 3) and torch.equal(out, w_out)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_result_does_not_depend_on_what_the_workspace_held(weights3, dtype):
     # the caller owns the workspace: NaN bit patterns everywhere must not leak into the result

@@ -79,6 +79,14 @@ def _uniform_pm(seed, stream, shape, bound, device="cpu"):
     return ((u * 2.0 - 1.0) * b).reshape(shape)
 
 
+def vgg16_shapes(c_in=3, n_classes=101, desc_dim=256):
+    """Tensor shapes of the reference's architecture: 13 conv layers of VGG-16 'D' + the four Linear layers of
+    ``__swapClassifier__`` (Sheet03/spatialModel.py:136-152)."""
+    fcs = [(512 * 7 * 7, 4096), (4096, 4096), (4096, desc_dim), (desc_dim, n_classes)]
+    return dict(conv_w=[(co, ci, 3, 3) for (ci, co) in VGG16_CONVS], conv_b=[(co,) for (_, co) in VGG16_CONVS],
+                fc_w=[(fo, fi) for (fi, fo) in fcs], fc_b=[(fo,) for (_, fo) in fcs])
+
+
 def synth_vgg16_weights(c_in=3, n_classes=101, desc_dim=256, seed=1, device="cpu"):
     """Random-init weights of the reference's architecture (Sheet03/spatialModel.py:110,136-152).
 
@@ -96,7 +104,7 @@ def synth_vgg16_weights(c_in=3, n_classes=101, desc_dim=256, seed=1, device="cpu
         conv_w.append(_uniform_pm(seed, sid, (co, ci, 3, 3), math.sqrt(6.0 / fan_in), device)); sid += 1
         bfan = (c_in * 9) if li == 0 else fan_in
         conv_b.append(_uniform_pm(seed, sid, (co,), 1.0 / math.sqrt(bfan), device)); sid += 1
-    for (fi, fo) in [(512 * 7 * 7, 4096), (4096, 4096), (4096, desc_dim), (desc_dim, n_classes)]:
+    for (fo, fi) in vgg16_shapes(c_in, n_classes, desc_dim)["fc_w"]:
         fc_w.append(_uniform_pm(seed, sid, (fo, fi), math.sqrt(6.0 / fi), device)); sid += 1
         fc_b.append(_uniform_pm(seed, sid, (fo,), 1.0 / math.sqrt(fi), device)); sid += 1
     return dict(conv_w=conv_w, conv_b=conv_b, fc_w=fc_w, fc_b=fc_b)

@@ -318,9 +318,24 @@ class _FusedHead(object):
         self.desc, self.logits = desc, logits
 
 
+def classifier_modules(desc_dim, n_classes):
+    """The module list ``__swapClassifier__`` builds (Sheet03/spatialModel.py:136-152 = temporalModel.py:165-181), as
+    data: what the ten stages of ``classifier_list()`` stand for and what shapes ``fc_w`` / ``fc_b`` must have.  Pinned to
+    the reference's own method run on a stub model (tests/golden/reference_model_kats.json)."""
+    dims = [(512 * 7 * 7, 4096), (4096, 4096), (4096, desc_dim), (desc_dim, n_classes)]
+    mods = []
+    for i, (fin, fout) in enumerate(dims):
+        mods.append({"type": "Linear", "in_features": fin, "out_features": fout, "bias": True})
+        if i < 3:
+            mods.append({"type": "ReLU", "inplace": True})
+            mods.append({"type": "Dropout", "p": 0.5})
+    return mods
+
+
 class _ClassifierStage(object):
     def __init__(self, stream, index):
         self.stream, self.index = stream, index
+        self.module = classifier_modules(stream.desc_dim, stream.n_classes)[index]  # what the reference has at this index
 
     def __call__(self, op):
         st = self.stream
