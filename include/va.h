@@ -62,6 +62,9 @@ extern "C" {
 typedef struct va_ctx va_ctx;
 typedef struct va_vgg16 va_vgg16;
 
+/* version number (currently 3) + VA_VERSION_EXPERIMENTS when the library was built with -DVA_EXPERIMENTS, i.e. when it
+ * also holds the measured-slower kernel families behind va_tvl1_params.tuning / VA_OPT_BF16_VARIANT 6 */
+#define VA_VERSION_EXPERIMENTS 0x10000
 int va_version(void);
 const char* va_last_error(void);
 int va_ctx_create(int device, va_ctx** out);
@@ -169,29 +172,12 @@ typedef struct va_tvl1_params {
                          register tiles; fixed-iteration mode only.  Bit 9 (512): iterate every level that fits one
                          strip (<= 256 columns) with the persistent row pipeline k_iter_rows, the others with the
                          streaming kernel.  0 (default) = library choice per level.  Results do not depend on it. */
-    /* Explicit tuning / test switches of the row pipeline (k_iter_stream); the library reads no environment variable.
-       Results do not depend on any of them. */
-    int stream_levels; /* -1 (default): the library decides per level; otherwise a bit set: bit s = pyramid level s
-                          (0 = full resolution) iterates with the row pipeline, every other level on the register tiles */
-    int stream_waves;  /* 0 (default): two-wave pipeline (16 iterations per pass) where a level has at most two strips,
-                          one-wave (10 per pass) elsewhere; 1: one-wave pipeline everywhere; 3: where the two-wave
-                          pipeline would run, ONE wave with all 16 levels and a whole SIMD's registers (measured slower);
-                          4: the two-wave pipeline in 512-thread workgroups of FOUR jobs each, the two waves of a job on the
-                          same SIMD (k_iter_stream4; measured 2 % slower) */
-    int stream_chunks; /* 0 (default): rows cut into as many chunks as fill the GPU; n > 0: n chunks (capped at h/32) */
-    int stream_slots;  /* 0 (default): target number of strip x chunk x pair jobs per call (640 two-wave / 1024 one-wave) */
-    /* The persistent row pipeline (k_iter_rows: all `iters` iterations of a warp step in one launch, one workgroup per
-       pair; levels of at most 256 columns, fixed-iteration mode). */
-    int rows_levels;   /* -1 (default): the library decides per level; otherwise a bit set as stream_levels: bit s =
-                          level s iterates with k_iter_rows where it applies (takes precedence over stream_levels) */
-    int stream_ppl;    /* 0 or 2 (default): the row pipeline keeps 2 pixels per lane (128-column strips); 3: 192-column strips
-                          (a 129..192-column level then is one strip without x halo; measured no faster) */
-    int stream_queue;  /* 0 (default): the library decides; 1: the row pipeline runs ALL passes of a warp step in one launch,
-                          persistent workgroups pulling (pass, pair, strip, chunk) tasks from a queue, a pair's next pass
-                          starting as soon as that pair's previous pass is complete (k_iter_stream_q; stream_slots then is
-                          the number of persistent workgroups; bit-exact, measured slower); 2: one launch per pass */
-    int rows_cfg;      /* 0 (default): the library's pipeline shape; otherwise waves * 16 + levels per wave (one of the
-                          compiled shapes: 4x4, 2x8, 3x5, 4x3, 8x2, 2x6), i.e. waves x levels iterations per pass */
+    int tuning[8];    /* the library's own tuning / experiment switches (which kernel iterates which pyramid level, chunking of
+                         rows, pipeline shapes: named in csrc/va_internal.h, VA_TUNE_*); va_tvl1_default_params fills in the
+                         defaults (-1, 0, 0, 0, -1, 0, 0, 0) and callers leave them alone.  Results do not depend on any
+                         of them; the library reads no environment variable.  Several values select kernels that are
+                         only compiled with -DVA_EXPERIMENTS (measured slower, kept reproducible: DESIGN.md section 7);
+                         a default build rejects those with VA_ERR_INVALID. */
 } va_tvl1_params;
 
 void va_tvl1_default_params(va_tvl1_params* p);

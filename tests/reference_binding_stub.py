@@ -1,19 +1,3 @@
-# INTEGRATION — wiring `libva_hip.so` into the reference (Sheet03)
-
-The reference is plain Python (PyTorch tensors in, tensors out) with no FFI.  The drop-in boundary
-is the C ABI of `include/va.h`; a maintainer of `arindamrc/video_analytics` binds it with `ctypes`
-(PyTorch-ROCm tensors as the container type: `tensor.data_ptr()` and the current HIP stream).
-`video_analytics_amd/_ffi.py` is that binding, complete; the excerpt below is the minimum the
-reference itself would add.
-
-## 1. Binding stub (reference side)
-
-The stub is a real file, `tests/reference_binding_stub.py` (what the reference would hold as `Sheet03/va_hip.py`), quoted here
-verbatim (`tests/test_abi.py` keeps the quote in sync) and EXECUTED by `tests/test_binding_stub_gpu.py`: a CPU-resident
-`nn.Sequential` VGG-16 'D' with the `__swapClassifier__` head is bound through it alone and matches the oracle within 1e-3;
-its `flow_volumes` equals the product path bit for bit.
-
-```python
 # Sheet03/va_hip.py -- the file a maintainer of arindamrc/video_analytics adds to bind libva_hip.so (include/va.h).
 # Kept under tests/ so that it is EXECUTED: tests/test_binding_stub_gpu.py builds a CPU-resident torch VGG-16 +
 # __swapClassifier__ head, binds it through this file alone (no video_analytics_amd._ffi) and compares with the oracle;
@@ -95,55 +79,3 @@ def flow_volumes(gray):                           # gray: cuda uint8 [B, L+1, H,
     stack = torch.empty(2 * B * (F - 1), H, W, device=gray.device)
     _chk(_L.va_flow_to_stack(_ctx, flow.data_ptr(), B * (F - 1), W, H, 20.0, 0.485, 0.229, stack.data_ptr(), st))
     return stack.view(B, 2 * (F - 1), H, W)       # what TemporalDataset.__getitem__ stacks (Sheet03/temporalModel.py:83-90)
-```
-
-## 2. Call-site changes in the reference
-
-| reference lines | change |
-|---|---|
-| `Sheet03/spatialModel.py:127-129`, `Sheet03/temporalModel.py:140-142` | after `__swapClassifier__` (and `__copyFirstLayer__`): `self.hip = HipVgg(self.model)` |
-| `Sheet03/spatialModel.py:212-218`, `Sheet03/temporalModel.py:241-247` (inside `validate()`) | `op = self.hip.features(ip)`; `featureVectors, op = self.hip.classify(op)` — replaces `self.features(ip)`, `view`, and the two `classifierList` loops (Dropout is the identity in `eval()`, `:201`) |
-| `Sheet03/temporalModel.py:76-90` (`TemporalDataset.__getitem__`) | optional: instead of opening 20 flow JPEGs, hand the loader 11 gray frames and call `va_tvl1_flow` + `va_flow_to_stack` on the batch (`video_analytics_amd.temporalModel.flowVolumesFromFrames`) |
-| `Sheet03/temporalModel.py:155-161` | optional: `va_copy_first_layer` on the device |
-| `Sheet03/spatialModel.py:219-221` | optional: `va_validate_batch` (no per-batch `.item()` sync) |
-| `Sheet03/spatialModel.py:223-228`, `Sheet03/temporalModel.py:252-257` (the `AverageMeter` loop of `validate()`) | optional: keep a `[n_videos,256]` f32 sum buffer + i32 counts on the device and call `va_meter_update(desc, slot, ...)` per batch (slot = index of the clip's video in the list), `va_meter_average` once before `saveVideoDescriptors`: no `featureVectors[i].cpu()` per clip |
-| `Sheet03/combinedModel.py:38` (`classifier.predict(testDescriptors)`) | optional: `va_linear_svm_predict(X, coef_, intercept_)` → index into `classifier.classes_`; `fit` (`:34-35`) stays sklearn |
-
-| `Sheet03/spatialModel.py:165-182` (the batch loop of `train()`: forward, `criterion`, `zero_grad`, `backward`, `optimizer.step()`) | optional: one `va_vgg16_train_step(model, ip, 0, labels, B, lr, momentum, seed, featureVectors, stats, ws, ...)` per batch after `va_vgg16_train_init`; `lr` is `optimizer.param_groups[0]["lr"]`; `save()`/`resume()` exchange `model.state_dict()` / the momentum buffers through `va_vgg16_export_state` / `va_vgg16_import_state` |
-
-Without that last row `train()` keeps using the torch modules and only inference runs on the library.
-
-## 3. Entry points ↔ reference interfaces
-
-See the header comment of `include/va.h` (one line per entry point with the `file:line` it stands
-behind) and `DESIGN.md` §1.
-
-## 4. Build and placement
-
-`python -c "import __graft_entry__ as g; g.build()"` (or `make -C video_analytics_amd/csrc`) builds
-`video_analytics_amd/libva_hip.so` with `hipcc --offload-arch=gfx950 -ffp-contract=off`.  The library
-needs ROCm ≥ 7.0 and an MI355X (`va_ctx_create` rejects other architectures); it links only
-`libamdhip64.so.7`, resolved to the copy torch already loaded.
-
-## 4a. What the library does NOT do
-
-It reads no environment variable and keeps no process-global switch: every tuning or test knob is a field of
-`va_tvl1_params` or a `va_vgg16_set_option(model, option, value)` of one handle (`include/va.h`).  Every entry point
-selects its context's device itself (`hipSetDevice`); pass the stream of THAT device (`torch.cuda.current_stream(device)`).
-
-## 4b. Running on several GPUs
-
-One process per GPU, clips sharded in contiguous blocks, ONE all-gather of the `[n_local, 2, 101]` scores at the end
-(`video_analytics_amd/dist.py`, `sweep.py`).  `python bench.py --gpus N` starts the N ranks itself
-(`video_analytics_amd/launch.py`); `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` works as well.
-
-## 5. Error and ownership conventions
-
-Return 0 / nonzero + `va_last_error()` (thread-local).  Bad shapes/arguments → code 1/3 → the Python
-wrapper raises `ValueError` (as `Sheet03/spatialModel.py:46`, `Sheet03/utils.py:56` do); HIP failures
-→ code 2 → `RuntimeError`; code 4 (`VA_ERR_STOPPED`: a test switch cut a training step short) → `RuntimeError`.  Class labels
-outside `[0, n_classes)` (the datasets return the list files' raw 1-based labels): host tensors → `ValueError` before the
-call, device tensors → NaN loss, no out-of-bounds read.  The caller owns inputs, outputs and workspaces; the library owns the
-context and the packed-weight handle; forward/flow calls allocate nothing and never synchronise the
-host (graph-capturable, except the optional profiling hooks).  One process per GPU; a handle is used
-by one thread at a time.

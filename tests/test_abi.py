@@ -74,11 +74,17 @@ def test_tile_plan_of_the_benchmark_pyramid():
     # 143^2 (strips 56 % full) and 91^2 (too few jobs) iterate on 64x64 register tiles -- the measured choice
     assert [(d["tile_w"], d["tile_h"], d["waves"], d["block_iters"], d["tiles_x"]) for d in plan] == [
         (128, 0, 2, 16, 2), (128, 0, 2, 16, 2), (64, 64, 4, 12, 3), (128, 0, 2, 16, 1), (64, 64, 4, 16, 2)]
-    rows = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 9))  # k_iter_rows: 4, 3, 3, 2, 2 px per lane
-    assert [(d["tile_w"], d["tile_h"], d["waves"], d["block_iters"]) for d in rows] == [(256, 0, 4, 16), (192, 0, 4, 16), (192, 0, 4, 16),
-                                                                                          (128, 0, 4, 16), (128, 0, 4, 16)]
-    ppl3 = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 8, stream_ppl=3))
-    assert [(d["tile_w"], d["block_iters"], d["tiles_x"]) for d in ppl3] == [(192, 10, 2), (192, 10, 1), (192, 10, 1), (192, 10, 1), (192, 10, 1)]
+    if _ffi.has_experiments():  # `make EXPERIMENTS=1`: the measured-slower kernel families are compiled in
+        rows = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 9))  # k_iter_rows: 4, 3, 3, 2, 2 px per lane
+        assert [(d["tile_w"], d["tile_h"], d["waves"], d["block_iters"]) for d in rows] == [(256, 0, 4, 16), (192, 0, 4, 16), (192, 0, 4, 16),
+                                                                                              (128, 0, 4, 16), (128, 0, 4, 16)]
+        ppl3 = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 8, stream_ppl=3))
+        assert [(d["tile_w"], d["block_iters"], d["tiles_x"]) for d in ppl3] == [(192, 10, 2), (192, 10, 1), (192, 10, 1), (192, 10, 1), (192, 10, 1)]
+    else:  # a default build refuses the experiment switches loudly instead of silently running something else
+        for kw in (dict(tile_mask=1 << 9), dict(stream_ppl=3), dict(stream_waves=3), dict(stream_waves=4), dict(stream_queue=1),
+                   dict(rows_levels=1), dict(rows_cfg=40)):
+            assert _ffi.lib().va_tvl1_workspace_bytes(224, 224, 1, 2, _ffi.default_tvl1_params(epsilon=0.0, **kw)) == 0, kw
+            assert b"VA_EXPERIMENTS" in _ffi.lib().va_last_error()
     everywhere = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 8))
     assert [(d["tile_w"], d["tiles_x"]) for d in everywhere] == [(128, 2), (128, 2), (128, 2), (128, 1), (128, 1)]
     hd = flow.tile_plan(1280, 720, _ffi.default_tvl1_params(epsilon=0.0))  # wide levels: one wave, 10 per pass, halo 10
@@ -110,3 +116,11 @@ def test_public_header_is_plain_c(tmp_path):
     r = subprocess.run([cc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                         "-o", str(tmp_path / "t.o")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_integration_md_quotes_the_executed_binding_stub():
+    """INTEGRATION.md section 1 shows tests/reference_binding_stub.py verbatim (the file tests/test_binding_stub_gpu.py
+    executes): the documented reference-side binding is tested code."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = open(os.path.join(ROOT, "tests", "reference_binding_stub.py")).read()
+    assert "```python\n" + stub + "```" in md

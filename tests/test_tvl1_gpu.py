@@ -19,6 +19,14 @@ def _frames(n_seq, n_frames, H, W, seed):
 
 
 # tuning fields of va_tvl1_params the oracle has no counterpart for (results must not depend on them)
+def _needs_experiments():
+    """The measured-slower kernel families (k_iter_rows, k_iter_stream_q, k_iter_stream4, one deep wave, 3 pixels per
+    lane) are only in a library built with `make -C video_analytics_amd/csrc EXPERIMENTS=1` (va_version() says so)."""
+    from video_analytics_amd import _ffi
+    if not _ffi.has_experiments():
+        pytest.skip("libva_hip.so built without -DVA_EXPERIMENTS")
+
+
 PRODUCT_ONLY = ("block_iters", "tile_mask", "stream_levels", "stream_waves", "stream_chunks", "stream_slots", "stream_ppl", "stream_queue", "rows_levels", "rows_cfg")
 
 
@@ -86,6 +94,8 @@ def test_streaming_kernel_bit_exact(oracle_tvl1, H, W, nch):
 @pytest.mark.parametrize("H,W,nch", [(179, 179, 0), (143, 143, 2), (100, 64, 3), (64, 300, 1), (150, 400, 3), (57, 131, 1), (33, 190, 1),
                                      (129, 225, 2), (40, 700, 1), (16, 16, 0)])
 def test_streaming_kernel_pixels_per_lane_bit_exact(oracle_tvl1, ppl, H, W, nch):
+    if ppl == 3:
+        _needs_experiments()
     # k_iter_stream with 2 and 3 pixels per lane (strips of 128 / 192 columns; a shallower pipeline for 3):
     # one strip without halo (179, 143, 131 columns at 3 per lane), several strips with halos that are multiples of the
     # pixels per lane, chunks of rows, ragged widths whose pitch is padded to a multiple of 12 for 3 per lane
@@ -98,6 +108,7 @@ def test_streaming_kernel_pixels_per_lane_bit_exact(oracle_tvl1, ppl, H, W, nch)
 
 @pytest.mark.parametrize("H,W,nch", [(224, 224, 0), (100, 64, 3), (129, 225, 2), (57, 131, 1), (179, 179, 2)])
 def test_streaming_kernel_one_deep_wave_bit_exact(oracle_tvl1, H, W, nch):
+    _needs_experiments()
     # stream_waves = 3: ONE wave carries all 16 levels (whole register file of its SIMD, no hand-over, no barrier)
     gray = _frames(1, 3, H, W, seed=H + 3 * W)
     for iters, warps, nscales in ((10, 1, 1), (37, 2, 3)):
@@ -109,6 +120,7 @@ def test_streaming_kernel_one_deep_wave_bit_exact(oracle_tvl1, H, W, nch):
 @pytest.mark.parametrize("H,W,nch,nseq", [(224, 224, 0, 1), (224, 224, 2, 3), (100, 64, 3, 1), (129, 225, 2, 2), (57, 131, 1, 5), (179, 179, 2, 1),
                                           (114, 114, 3, 2), (40, 40, 1, 1)])
 def test_four_jobs_per_workgroup_bit_exact(oracle_tvl1, H, W, nch, nseq):
+    _needs_experiments()
     # stream_waves = 4: k_iter_stream4 -- 512-thread workgroups run four (strip, chunk, pair) jobs each, the two waves of a job on
     # the same SIMD; job counts that are not multiples of four (padding jobs), chunks of different lengths in one workgroup
     # (padded step counts), several pairs per workgroup
@@ -122,6 +134,7 @@ def test_four_jobs_per_workgroup_bit_exact(oracle_tvl1, H, W, nch, nseq):
 @pytest.mark.parametrize("H,W,nch,slots", [(224, 224, 0, 0), (224, 224, 2, 3), (100, 64, 3, 2), (129, 225, 2, 7), (57, 131, 1, 1), (179, 179, 2, 0),
                                            (114, 114, 3, 5)])
 def test_queued_row_pipeline_bit_exact(oracle_tvl1, H, W, nch, slots):
+    _needs_experiments()
     # stream_queue = 1: k_iter_stream_q runs all passes of a warp step in ONE launch; persistent workgroups pull (pass,
     # pair, strip, chunk) tasks, a pair's next pass starting when that pair's previous pass is complete (per-pair
     # counters, agent-scope release / acquire between workgroups).  Few persistent workgroups (1..7: every hand-over is
@@ -136,6 +149,7 @@ def test_queued_row_pipeline_bit_exact(oracle_tvl1, H, W, nch, slots):
 
 
 def test_queued_row_pipeline_full_schedule(oracle_tvl1):
+    _needs_experiments()
     from video_analytics_amd import flow as vflow
     gray = _frames(4, 3, 224, 224, seed=5)
     ref = oracle_tvl1.tvl1_flow(gray.numpy(), oracle_tvl1.default_params(epsilon=0.0), nthreads=8)
@@ -149,6 +163,7 @@ ROWS_SHAPES = [0, 4 * 16 + 4, 2 * 16 + 8, 3 * 16 + 5, 4 * 16 + 3, 8 * 16 + 2, 2 
 @pytest.mark.parametrize("H,W", [(48, 64), (100, 64), (224, 224), (57, 131), (179, 179), (143, 143), (114, 114), (91, 91),
                                  (33, 130), (24, 16), (129, 225), (200, 256), (40, 190)])
 def test_persistent_row_pipeline_bit_exact(oracle_tvl1, H, W):
+    _needs_experiments()
     # tile_mask bit 9 forces k_iter_rows (all iterations of a warp step in one launch, passes chained inside the kernel)
     # on every level it applies to: 2, 3 and 4 pixels per lane (widths up to 128 / 192 / 256), ragged widths with pitch
     # padding, heights just above and below the minimum for the default shape (levels that do not qualify fall back
@@ -163,6 +178,7 @@ def test_persistent_row_pipeline_bit_exact(oracle_tvl1, H, W):
 @pytest.mark.parametrize("cfg", ROWS_SHAPES)
 @pytest.mark.parametrize("n", [224, 179, 91])
 def test_every_row_pipeline_shape_bit_exact(oracle_tvl1, cfg, n):
+    _needs_experiments()
     # every compiled waves x levels shape on the benchmark's 4-, 3- and 2-pixel-per-lane levels; 37 iterations = a short
     # first pass plus full passes for every shape's depth (8 .. 16); also the 1-ulp arithmetic variant against the
     # register tiles' (the same operations in both kernels)
@@ -176,6 +192,7 @@ def test_every_row_pipeline_shape_bit_exact(oracle_tvl1, cfg, n):
 
 
 def test_row_pipeline_full_schedule_and_mixed_levels(oracle_tvl1):
+    _needs_experiments()
     # the benchmark schedule (5 scales x 5 warps x 300 iterations: 19 chained passes per launch) on the benchmark's
     # frame size, all levels on k_iter_rows; then mixed with the other two kernels level by level (layouts convert at
     # the level transitions)

@@ -26,6 +26,13 @@ EXPORTS = [
 ]
 
 
+# names of the slots of va_tvl1_params.tuning (csrc/va_internal.h, VA_TUNE_*): the library's own tuning / experiment
+# switches, addressed by name from tests and tools (``default_tvl1_params(stream_levels=1)``)
+TUNING_SLOTS = ("stream_levels", "stream_waves", "stream_chunks", "stream_slots", "rows_levels", "stream_ppl",
+                "stream_queue", "rows_cfg")
+VA_VERSION_EXPERIMENTS = 0x10000
+
+
 class Tvl1Params(ctypes.Structure):
     """Mirror of ``va_tvl1_params`` (include/va.h)."""
     _fields_ = [
@@ -40,15 +47,22 @@ class Tvl1Params(ctypes.Structure):
         ("block_iters", ctypes.c_int),
         ("fast_math", ctypes.c_int),
         ("tile_mask", ctypes.c_int),
-        ("stream_levels", ctypes.c_int),
-        ("stream_waves", ctypes.c_int),
-        ("stream_chunks", ctypes.c_int),
-        ("stream_slots", ctypes.c_int),
-        ("rows_levels", ctypes.c_int),
-        ("stream_ppl", ctypes.c_int),
-        ("stream_queue", ctypes.c_int),
-        ("rows_cfg", ctypes.c_int),
+        ("tuning", ctypes.c_int * 8),
     ]
+
+
+def _tuning_property(i):
+    return property(lambda self: self.tuning[i], lambda self, v: self.tuning.__setitem__(i, int(v)))
+
+
+for _i, _name in enumerate(TUNING_SLOTS):
+    setattr(Tvl1Params, _name, _tuning_property(_i))
+
+
+def has_experiments():
+    """True when libva_hip.so was built with -DVA_EXPERIMENTS (`make -C video_analytics_amd/csrc EXPERIMENTS=1`): the
+    measured-slower kernel families of DESIGN.md section 7 are then compiled in and their tuning values accepted."""
+    return bool(lib().va_version() & VA_VERSION_EXPERIMENTS)
 
 
 _lib = None

@@ -1183,6 +1183,7 @@ __global__ void __launch_bounds__(NWV * 64)
     stream_job<PPL, KH, NWV, FAST>(a, a.pair0 + (int)(lid / gridDim.x), (int)(lid % gridDim.x), a.K, a.sin, a.sout);
 }
 
+#ifdef VA_EXPERIMENTS  // measured-slower kernel families: k_iter_stream4, k_iter_stream_q, k_iter_rows
 // Four jobs per 512-thread workgroup (see stream_job, SUBS): gridDim.x workgroups cover a.njobs4 = 4 gridDim.x (>= jobs x
 // pairs) flattened jobs; the ones beyond the call's jobs are padding.
 template <bool FAST>
@@ -1543,6 +1544,8 @@ __global__ void __launch_bounds__(NWV * 64) k_iter_rows(RowsArgs a)
     }
 }
 
+#endif  // VA_EXPERIMENTS
+
 // ---------------------------------------------------------------- host side -------------------
 
 struct TileCfg {
@@ -1674,14 +1677,20 @@ struct StreamPick {
 int stream_ppl(const va_tvl1_params* p, int w)
 {
     (void)w;
-    return p->stream_ppl == 3 ? 3 : 2;
+    return p->tuning[VA_TUNE_STREAM_PPL] == 3 ? 3 : 2;
 }
 template <bool TWO, bool FAST>
 void launch_stream(int ppl, dim3 grid, hipStream_t st, const StreamArgs& sa)
 {
     constexpr int NWV = TWO ? 2 : 1;
-    if (ppl == 3) k_iter_stream<3, TWO ? stream_kh2(3) : stream_k1(3), NWV, FAST><<<grid, NWV * 64, 0, st>>>(sa);
-    else k_iter_stream<2, TWO ? stream_kh2(2) : stream_k1(2), NWV, FAST><<<grid, NWV * 64, 0, st>>>(sa);
+#ifdef VA_EXPERIMENTS
+    if (ppl == 3) {
+        k_iter_stream<3, TWO ? stream_kh2(3) : stream_k1(3), NWV, FAST><<<grid, NWV * 64, 0, st>>>(sa);
+        return;
+    }
+#endif
+    (void)ppl;
+    k_iter_stream<2, TWO ? stream_kh2(2) : stream_k1(2), NWV, FAST><<<grid, NWV * 64, 0, st>>>(sa);
 }
 // Strips of a level.  Two-wave pipeline (16 iterations per pass) where the deeper x halo costs nothing, i.e. where the
 // level has no interior strip (w <= 224); wider levels use the one-wave pipeline (10 per pass, halo 10: measured on
@@ -1690,10 +1699,10 @@ void stream_strips(const va_tvl1_params* p, int w, StreamPick& sp)
 {
     sp.ppl = stream_ppl(p, w);
     const int SW = 64 * sp.ppl, hq = sp.ppl == 3 ? 3 : 2;  // strip origins stay multiples of the pixels per lane
-    sp.two = p->stream_waves != 1 && tiles_1d(w, SW, va_cdiv(2 * stream_kh2(sp.ppl), hq) * hq) <= 2;
+    sp.two = p->tuning[VA_TUNE_STREAM_WAVES] != 1 && tiles_1d(w, SW, va_cdiv(2 * stream_kh2(sp.ppl), hq) * hq) <= 2;
     // stream_waves == 3 (experiment): where the two-wave pipeline would run, ONE wave with all 16 levels and the whole
     // register file of its SIMD (no hand-over, no barrier)
-    sp.deep1 = sp.two && p->stream_waves == 3 && sp.ppl == 2;
+    sp.deep1 = sp.two && p->tuning[VA_TUNE_STREAM_WAVES] == 3 && sp.ppl == 2;
     // (Also measured, round 2, and removed again: THREE waves of 4 / 5 levels each -- 12 / 15 iterations per pass at 144 /
     // 168 registers, i.e. three resident waves per SIMD instead of two: 45.2 / 43.9 ms on the 224^2 level and 35.3 / 34.8
     // on 179^2 against 41.6 / 32.9 for the two-wave form: more resident waves do not fill the idle issue slots.)
@@ -1707,8 +1716,8 @@ StreamPick pick_stream(const va_tvl1_params* p, int w, int h, int npairs)
     // chunks of rows: the number of jobs (strip x chunk x pair) that keeps the GPU busiest was measured with one and
     // with two concurrent calls on different HIP streams: ~1024 one-wave jobs, ~640 two-wave jobs per call (256 CUs x
     // 8 waves); rows per chunk not below 32
-    const int slots = p->stream_slots > 0 ? p->stream_slots : (sp.two ? 640 : 1024);
-    int nch = p->stream_chunks;
+    const int slots = p->tuning[VA_TUNE_STREAM_SLOTS] > 0 ? p->tuning[VA_TUNE_STREAM_SLOTS] : (sp.two ? 640 : 1024);
+    int nch = p->tuning[VA_TUNE_STREAM_CHUNKS];
     if (nch <= 0) nch = (int)((double)slots / ((double)npairs * sp.nsx) + 0.5);
     if (nch > h / 32) nch = h / 32;
     if (nch < 1) nch = 1;
@@ -1724,7 +1733,7 @@ bool level_streams(const va_tvl1_params* p, bool eps, int s, int w, int h, size_
     if (eps || (double)plane * kNF_STATE * sizeof(float) >= 2147483648.0) return false;  // 32-bit buffer offsets
     if (p->tile_mask & kStreamBit) return true;
     if (p->tile_mask != 0) return false;
-    if (p->stream_levels >= 0) return ((p->stream_levels >> s) & 1) != 0;
+    if (p->tuning[VA_TUNE_STREAM_LEVELS] >= 0) return ((p->tuning[VA_TUNE_STREAM_LEVELS] >> s) & 1) != 0;
     StreamPick sp{};
     stream_strips(p, w, sp);
     // measured per level of the 224x224 pyramid (320 pairs, two streams; profiles/README.md): the row pipeline wins on 224^2
@@ -1739,6 +1748,7 @@ constexpr int kRowsBit = 1 << 9;  // va_tvl1_params.tile_mask bit: iterate with 
 struct RowsPick {
     int ppl, nwv, kh, K, K0, N;
 };
+#ifdef VA_EXPERIMENTS
 // pipeline shapes compiled in (waves x levels per wave); rows_cfg = waves * 16 + levels per wave, 0 = the default
 constexpr int kRowsShapes[][2] = {{4, 4}, {2, 8}, {3, 5}, {4, 3}, {8, 2}, {2, 6}};
 constexpr int kNumRowsShapes = (int)(sizeof(kRowsShapes) / sizeof(kRowsShapes[0]));
@@ -1748,12 +1758,17 @@ constexpr int rows_lds_bytes(int ppl, int nwv, int kh)
     return (nwv * kh + nwv) * kNF_RO * ppl * 256 + (nwv > 1 ? nwv - 1 : 1) * 2 * (kNF_STATE * ppl * 256 + 4);
 }
 constexpr int kRowsLdsMax = 160 * 1024 - 512;
+#endif
 bool pick_rows(const va_tvl1_params* p, int h, int pitch, RowsPick& rp)
 {
+#ifndef VA_EXPERIMENTS
+    (void)p, (void)h, (void)pitch, (void)rp;
+    return false;  // k_iter_rows is not compiled in
+#else
     int nwv = kRowsShapes[0][0], kh = kRowsShapes[0][1];
-    if (p->rows_cfg > 0) {
-        nwv = p->rows_cfg >> 4;
-        kh = p->rows_cfg & 15;
+    if (p->tuning[VA_TUNE_ROWS_CFG] > 0) {
+        nwv = p->tuning[VA_TUNE_ROWS_CFG] >> 4;
+        kh = p->tuning[VA_TUNE_ROWS_CFG] & 15;
     }
     bool known = false;
     for (int i = 0; i < kNumRowsShapes; ++i) known = known || (kRowsShapes[i][0] == nwv && kRowsShapes[i][1] == kh);
@@ -1770,6 +1785,7 @@ bool pick_rows(const va_tvl1_params* p, int h, int pitch, RowsPick& rp)
     if (rp.N >= 2047 || pitch % rp.ppl != 0) return false;  // the pass index must fit the row identity; whole lanes per row
     // pass n + 1 reads a row back at least two steps after pass n stored it
     return h >= Kfull + nwv + 4 && h < (1 << kRowIdRowBits);
+#endif
 }
 
 enum { LK_TILE = 0, LK_STREAM = 1, LK_ROWS = 2 };
@@ -1783,13 +1799,14 @@ int level_kernel(const va_tvl1_params* p, bool eps, int s, int w, int h, int pit
     const bool rows_ok = pick_rows(p, h, pitch, *rp);
     if (p->tile_mask & kRowsBit) return rows_ok ? LK_ROWS : LK_STREAM;
     if (p->tile_mask != 0) return level_streams(p, eps, s, w, h, plane) ? LK_STREAM : LK_TILE;
-    if (p->rows_levels >= 0 || p->stream_levels >= 0) {
-        if (p->rows_levels >= 0 && ((p->rows_levels >> s) & 1) && rows_ok) return LK_ROWS;
-        return p->stream_levels >= 0 && ((p->stream_levels >> s) & 1) ? LK_STREAM : LK_TILE;
+    if (p->tuning[VA_TUNE_ROWS_LEVELS] >= 0 || p->tuning[VA_TUNE_STREAM_LEVELS] >= 0) {
+        if (p->tuning[VA_TUNE_ROWS_LEVELS] >= 0 && ((p->tuning[VA_TUNE_ROWS_LEVELS] >> s) & 1) && rows_ok) return LK_ROWS;
+        return p->tuning[VA_TUNE_STREAM_LEVELS] >= 0 && ((p->tuning[VA_TUNE_STREAM_LEVELS] >> s) & 1) ? LK_STREAM : LK_TILE;
     }
     return level_streams(p, eps, s, w, h, plane) ? LK_STREAM : LK_TILE;
 }
 
+#ifdef VA_EXPERIMENTS
 template <int PPL, bool FAST>
 int launch_rows(const RowsPick& rp, const RowsArgs& a, int npairs, hipStream_t st)
 {
@@ -1810,6 +1827,7 @@ int launch_rows(const RowsPick& rp, const RowsArgs& a, int npairs, hipStream_t s
     va_set_error("va_tvl1_flow: row pipeline shape %dx%d is not compiled in", rp.nwv, rp.kh);
     return VA_ERR_INVALID;
 }
+#endif
 
 // Pairs per chunk of a level: the iteration launches of a chunk re-read what the previous launch wrote, so a chunk
 // whose state (64 B per pixel) stays within ~150 MB (70, 110, 200 MB measured slower) is served largely by the Infinity Cache (measured on the 179^2
@@ -1885,14 +1903,21 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
     VA_CHECK_ARG(p->block_iters >= 0 && p->block_iters <= 64, "va_tvl1: block_iters must be in [0,64]");
     VA_CHECK_ARG(p->fast_math == 0 || p->fast_math == 1, "va_tvl1: fast_math must be 0 or 1");
     VA_CHECK_ARG(p->tile_mask >= 0 && p->tile_mask < (1 << (kNumCfgs + 2)), "va_tvl1: tile_mask must be in [0, %d]", (1 << (kNumCfgs + 2)) - 1);
-    VA_CHECK_ARG(p->rows_levels >= -1 && p->rows_levels < (1 << kMaxScales) && p->rows_cfg >= 0 && p->rows_cfg < 256,
+    VA_CHECK_ARG(p->tuning[VA_TUNE_ROWS_LEVELS] >= -1 && p->tuning[VA_TUNE_ROWS_LEVELS] < (1 << kMaxScales) && p->tuning[VA_TUNE_ROWS_CFG] >= 0 && p->tuning[VA_TUNE_ROWS_CFG] < 256,
                  "va_tvl1: rows_levels must be -1 or a level bit set, rows_cfg in [0,255]");
-    VA_CHECK_ARG(p->stream_ppl == 0 || p->stream_ppl == 2 || p->stream_ppl == 3, "va_tvl1: stream_ppl must be 0 (default), 2 or 3");
-    VA_CHECK_ARG(p->stream_queue >= 0 && p->stream_queue <= 2, "va_tvl1: stream_queue must be 0 (default), 1 (queued) or 2 (a launch per pass)");
-    VA_CHECK_ARG(p->stream_levels >= -1 && p->stream_levels < (1 << kMaxScales) && (p->stream_waves == 0 || p->stream_waves == 1 || p->stream_waves == 3 || p->stream_waves == 4) &&
-                     p->stream_chunks >= 0 && p->stream_slots >= 0,
-                 "va_tvl1: stream_levels must be -1 or a level bit set, stream_waves 0 or 1, stream_chunks and stream_slots >= 0");
+    VA_CHECK_ARG(p->tuning[VA_TUNE_STREAM_PPL] == 0 || p->tuning[VA_TUNE_STREAM_PPL] == 2 || p->tuning[VA_TUNE_STREAM_PPL] == 3, "va_tvl1: stream_ppl must be 0 (default), 2 or 3");
+    VA_CHECK_ARG(p->tuning[VA_TUNE_STREAM_QUEUE] >= 0 && p->tuning[VA_TUNE_STREAM_QUEUE] <= 2, "va_tvl1: stream_queue must be 0 (default), 1 (queued) or 2 (a launch per pass)");
+    VA_CHECK_ARG(p->tuning[VA_TUNE_STREAM_LEVELS] >= -1 && p->tuning[VA_TUNE_STREAM_LEVELS] < (1 << kMaxScales) && (p->tuning[VA_TUNE_STREAM_WAVES] == 0 || p->tuning[VA_TUNE_STREAM_WAVES] == 1 || p->tuning[VA_TUNE_STREAM_WAVES] == 3 || p->tuning[VA_TUNE_STREAM_WAVES] == 4) &&
+                     p->tuning[VA_TUNE_STREAM_CHUNKS] >= 0 && p->tuning[VA_TUNE_STREAM_SLOTS] >= 0,
+                 "va_tvl1: stream_levels must be -1 or a level bit set, stream_waves one of 0, 1, 3, 4, stream_chunks and stream_slots >= 0");
     VA_CHECK_ARG(p->tau / p->theta <= 1000.0f && p->lambda * p->theta <= 1000.0f, "va_tvl1: tau/theta and lambda*theta must be <= 1000");
+    if (!kVaExperiments) {
+        const int sw = p->tuning[VA_TUNE_STREAM_WAVES];
+        VA_CHECK_ARG(sw != 3 && sw != 4 && p->tuning[VA_TUNE_STREAM_PPL] != 3 && p->tuning[VA_TUNE_STREAM_QUEUE] != 1 &&
+                         p->tuning[VA_TUNE_ROWS_LEVELS] <= 0 && p->tuning[VA_TUNE_ROWS_CFG] == 0 && !(p->tile_mask & kRowsBit),
+                     "va_tvl1: this tuning value selects an experiment kernel (k_iter_rows, k_iter_stream_q, k_iter_stream4, one deep "
+                     "wave, 3 pixels per lane); build the library with -DVA_EXPERIMENTS (make EXPERIMENTS=1) to get them");
+    }
     return VA_OK;
 }
 
@@ -1977,14 +2002,14 @@ extern "C" void va_tvl1_default_params(va_tvl1_params* p)
     p->block_iters = 0;
     p->fast_math = 0;
     p->tile_mask = 0;
-    p->stream_levels = -1;
-    p->stream_waves = 0;
-    p->stream_chunks = 0;
-    p->stream_slots = 0;
-    p->rows_levels = -1;
-    p->rows_cfg = 0;
-    p->stream_ppl = 0;
-    p->stream_queue = 0;
+    p->tuning[VA_TUNE_STREAM_LEVELS] = -1;
+    p->tuning[VA_TUNE_STREAM_WAVES] = 0;
+    p->tuning[VA_TUNE_STREAM_CHUNKS] = 0;
+    p->tuning[VA_TUNE_STREAM_SLOTS] = 0;
+    p->tuning[VA_TUNE_ROWS_LEVELS] = -1;
+    p->tuning[VA_TUNE_ROWS_CFG] = 0;
+    p->tuning[VA_TUNE_STREAM_PPL] = 0;
+    p->tuning[VA_TUNE_STREAM_QUEUE] = 0;
 }
 
 extern "C" int va_tvl1_pyramid_sizes(int w, int h, const va_tvl1_params* p, int* ws, int* hs)
@@ -2165,6 +2190,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
             a.theta = p->theta;
             a.pair0 = c0;
             int launches = 0;
+#ifdef VA_EXPERIMENTS
             if (rows) {
                 RowsArgs ra{};
                 ra.ro = ro;
@@ -2191,6 +2217,9 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                 cur ^= rp.N & 1;
                 launches = 1;
             }
+#else
+            (void)rp, (void)st_lo;
+#endif
             if (strm) {
                 const StreamPick sp = pick_stream(p, lw, lh, nc);
                 StreamArgs sa{};
@@ -2209,11 +2238,13 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                 sa.theta = a.theta;
                 const dim3 grid(sp.nsx * sp.nch, nc);
                 const bool two = sp.two != 0;
+                bool queued = false;
+#ifdef VA_EXPERIMENTS
                 // the queued form (all passes in one launch): two-wave pipeline, 2 pixels per lane, and a last pass deep
                 // enough to end in the second wave
                 const int qK = 2 * kStreamKH2, qn = va_cdiv(p->iters, qK), qlast = p->iters - (qn - 1) * qK;
-                const bool queued = two && sp.ppl == 2 && !sp.deep1 && qlast > kStreamKH2 &&
-                                    (p->stream_queue == 1 || (p->stream_queue == 0 && VA_STREAM_QUEUE_DEFAULT));
+                queued = two && sp.ppl == 2 && !sp.deep1 && qlast > kStreamKH2 &&
+                         (p->tuning[VA_TUNE_STREAM_QUEUE] == 1 || (p->tuning[VA_TUNE_STREAM_QUEUE] == 0 && VA_STREAM_QUEUE_DEFAULT));
                 if (queued) {
                     unsigned* ctl = (unsigned*)(ws + P.off_ctl);
                     VA_HIP(hipMemsetAsync(ctl, 0, (size_t)P.ctl_words * sizeof(unsigned), st));
@@ -2228,14 +2259,15 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                     qa.Klast = qlast;
                     qa.npairs = nc;
                     qa.tpp = sp.nsx * sp.nch;
-                    const int want = p->stream_slots > 0 ? p->stream_slots : 512;  // persistent workgroups: half the GPU's 1024 slots per call
+                    const int want = p->tuning[VA_TUNE_STREAM_SLOTS] > 0 ? p->tuning[VA_TUNE_STREAM_SLOTS] : 512;  // persistent workgroups: half the GPU's 1024 slots per call
                     const int nwg = qa.npairs * qa.tpp < want ? qa.npairs * qa.tpp : want;
                     if (p->fast_math) k_iter_stream_q<2, kStreamKH2, 2, true><<<nwg, 128, 0, st>>>(qa);
                     else k_iter_stream_q<2, kStreamKH2, 2, false><<<nwg, 128, 0, st>>>(qa);
                     cur ^= qn & 1;
                     launches = 1;
                 }
-                const bool four = sp.ppl == 2 && (p->stream_waves == 4 || (p->stream_waves == 0 && VA_STREAM4_DEFAULT));
+                const bool four = sp.ppl == 2 && (p->tuning[VA_TUNE_STREAM_WAVES] == 4 || (p->tuning[VA_TUNE_STREAM_WAVES] == 0 && VA_STREAM4_DEFAULT));
+#endif
                 for (int it = queued ? p->iters : 0; it < p->iters;) {
                     const int rem = p->iters - it;
                     const int kh2 = stream_kh2(sp.ppl), k1 = stream_k1(sp.ppl);
@@ -2244,13 +2276,16 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                     sa.sin = state[cur];
                     sa.sout = state[cur ^ 1];
                     sa.rev = VA_REV ? (launches & 1) : 0;
+#ifdef VA_EXPERIMENTS
                     if (sp.deep1) {
                         k_iter_stream<2, 16, 1, false><<<grid, 64, 0, st>>>(sa);
                     } else if (w2 && four) {
                         const int njobs = (int)(grid.x * grid.y), g4 = va_cdiv(njobs, 4);
                         if (p->fast_math) k_iter_stream4<true><<<g4, 512, 0, st>>>(sa, (int)grid.x, njobs);
                         else k_iter_stream4<false><<<g4, 512, 0, st>>>(sa, (int)grid.x, njobs);
-                    } else if (w2) {
+                    } else
+#endif
+                    if (w2) {
                         if (p->fast_math) launch_stream<true, true>(sp.ppl, grid, st, sa);
                         else launch_stream<true, false>(sp.ppl, grid, st, sa);
                     } else {

@@ -14,7 +14,7 @@ void va_set_error(const char* fmt, ...)
 
 extern "C" const char* va_last_error(void) { return g_err; }
 
-extern "C" int va_version(void) { return 1; }
+extern "C" int va_version(void) { return 3 | (kVaExperiments ? VA_VERSION_EXPERIMENTS : 0); }
 
 extern "C" int va_ctx_create(int device, va_ctx** out)
 {
@@ -23,7 +23,8 @@ extern "C" int va_ctx_create(int device, va_ctx** out)
     int n = 0;
     VA_HIP(hipGetDeviceCount(&n));
     VA_CHECK_ARG(device >= 0 && device < n, "va_ctx_create: device %d out of range (%d visible)", device, n);
-    VA_HIP(hipSetDevice(device));
+    va_device_guard guard(device);  // (the caller's current device is restored on return)
+    VA_HIP(guard.err);
     hipDeviceProp_t prop;
     VA_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {

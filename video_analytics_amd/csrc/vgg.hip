@@ -1075,6 +1075,7 @@ __global__ void __launch_bounds__(512) k_conv3x3_pp_bf16(ConvArgsBf a)
     conv3x3_pp_body<NT, POOL>(a);
 }
 
+#ifdef VA_EXPERIMENTS
 // ---------------------------------------------------------------- bf16 conv3x3, two wave groups + halo brick -------
 //
 // An experiment kept as a tested option (VA_OPT_BF16_VARIANT 6), not a default.  Tap-major staging moves (pixels +
@@ -1266,6 +1267,7 @@ __global__ void __launch_bounds__(512) k_conv3x3_bpp_bf16(ConvArgsBf a)
 {
     conv3x3_bpp_body<LGTW, LGTH, NT, POOL>(a);
 }
+#endif  // VA_EXPERIMENTS
 
 // ---------------------------------------------------------------- bf16 conv3x3 with 64 input channels: weights resident ----
 //
@@ -1920,6 +1922,7 @@ int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const
         VA_LAUNCH_CHECK();
         return VA_OK;
     }
+#ifdef VA_EXPERIMENTS
     // variant 6: the two-group kernel on halo bricks (k_conv3x3_bpp_bf16) on the layers with >= 128 output channels and
     // 28 x 28 pixels or more (16 x 16 bricks; 8 x 8 of four images; 4 x 4 of sixteen)
     if ((variant == 6 || (variant == 0 && VA_BPP_DEFAULT)) && !L.xcol && !out_f32 && a.Cin % 32 == 0 && L.cout % 128 == 0 &&
@@ -1946,6 +1949,7 @@ int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const
         VA_LAUNCH_CHECK();
         return VA_OK;
     }
+#endif
     const long grid64 = (long)(L.cout / 64) * a.tiles_x * a.tiles_y * tiles_b;
     const int ksteps = 3 * a.taps_x * (a.Cin / 64);
     const bool autosel = variant == 0 || variant >= 5;  // (variants 5 .. 7 fall through to the automatic choice where they do not apply)
@@ -2284,6 +2288,7 @@ extern "C" int va_vgg16_set_option(va_vgg16* m, int option, int value)
     switch (option) {
         case VA_OPT_BF16_VARIANT:
             VA_CHECK_ARG((value >= 0 && value <= 2) || (value >= 5 && value <= 7), "va_vgg16_set_option: VA_OPT_BF16_VARIANT must be 0, 1, 2, 5, 6 or 7");
+            VA_CHECK_ARG(value != 6 || kVaExperiments, "va_vgg16_set_option: VA_OPT_BF16_VARIANT 6 (k_conv3x3_bpp_bf16) needs a library built with -DVA_EXPERIMENTS");
             m->bf16_variant = value;
             return VA_OK;
         case VA_OPT_BF16_FIRST_LAYER:

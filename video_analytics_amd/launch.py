@@ -82,13 +82,95 @@ def spawn_ranks(argv, world, env=None, timeout=None, poll_s=0.05):
     return rc
 
 
-def visible_gpus():
-    """Device count without initialising the HIP runtime in this (parent) process."""
-    import torch
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
+
+
+def _kfd_gpu_nodes(root=KFD_NODES, dev_dir="/dev/dri"):
+    """GPU agents of the KFD topology in node order: the nodes whose ``properties`` give ``simd_count > 0`` (CPU agents have
+    0) and whose render node this process may open (a container that is handed one GPU of eight still sees all eight in
+    sysfs, but only its own ``/dev/dri/renderD*``).  Pure file reads: no HIP, no HSA, no driver call."""
+    nodes = []
     try:
-        return int(torch.cuda.device_count())
-    except Exception:
-        return 0
+        names = sorted(os.listdir(root), key=lambda n: int(n) if n.isdigit() else 1 << 30)
+    except OSError:
+        return nodes
+    for name in names:
+        props = {}
+        try:
+            with open(os.path.join(root, name, "properties")) as f:
+                for line in f:
+                    kv = line.split()
+                    if len(kv) == 2:
+                        props[kv[0]] = kv[1]
+        except OSError:
+            continue  # (a node of another container's cgroup reads as permission denied)
+        try:
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+        except ValueError:
+            continue
+        if dev_dir is not None and minor >= 0:
+            node = os.path.join(dev_dir, "renderD%d" % minor)
+            if not (os.path.exists(node) and os.access(node, os.R_OK | os.W_OK)):
+                continue
+        nodes.append({"node": name, "unique_id": props.get("unique_id", "0"), "gfx_target_version": props.get("gfx_target_version")})
+    return nodes
+
+
+def _apply_visible_list(nodes, value):
+    """``ROCR_VISIBLE_DEVICES`` / ``HIP_VISIBLE_DEVICES`` semantics: a comma list of indices into ``nodes`` (or, for ROCr,
+    ``GPU-<unique id in hex>``); the list ends at the first entry that names no device (how ``-1`` hides every GPU)."""
+    out = []
+    for tok in value.split(","):
+        tok = tok.strip()
+        pick = None
+        if tok.upper().startswith("GPU-"):
+            want = tok[4:].lower().lstrip("0")
+            for n in nodes:
+                try:
+                    if format(int(n["unique_id"]), "x") == want:
+                        pick = n
+                except ValueError:
+                    pass
+        else:
+            try:
+                i = int(tok)
+                if 0 <= i < len(nodes):
+                    pick = nodes[i]
+            except ValueError:
+                pass
+        if pick is None or pick in out:
+            break
+        out.append(pick)
+    return out
+
+
+def visible_gpus(environ=None, root=KFD_NODES, dev_dir="/dev/dri"):
+    """Number of GPUs a child process will see, WITHOUT touching HIP in this (parent) process: the KFD topology in
+    sysfs (``simd_count > 0``, render node accessible) filtered by ``ROCR_VISIBLE_DEVICES`` and then by
+    ``HIP_VISIBLE_DEVICES`` / ``CUDA_VISIBLE_DEVICES`` the way the runtimes apply them.  (``torch.cuda.device_count()``
+    would call ``hipGetDeviceCount`` here; a process that has initialised the GPU must not start the ranks by exec on
+    this pool, and is not provably GPU-free afterwards.)"""
+    environ = os.environ if environ is None else environ
+    nodes = _kfd_gpu_nodes(root, dev_dir)
+    if environ.get("ROCR_VISIBLE_DEVICES") is not None:
+        nodes = _apply_visible_list(nodes, environ["ROCR_VISIBLE_DEVICES"])
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if environ.get(var) is not None:
+            nodes = _apply_visible_list(nodes, environ[var])
+            break
+    return len(nodes)
+
+
+def gpu_runtime_loaded():
+    """True when this process has mapped the HIP or HSA runtime (what the launcher's parent must never do)."""
+    try:
+        with open("/proc/self/maps") as f:
+            maps = f.read()
+    except OSError:
+        return False
+    return "libamdhip64" in maps or "libhsa-runtime64" in maps
 
 
 def self_spawn(n_ranks, script, args):
