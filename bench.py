@@ -14,14 +14,19 @@ started by this script itself when it is run bare, or by torch.distributed.run) 
 step (weak scaling) and the timed region ends with ONE RCCL all-gather of all per-clip class scores.
 
 Prints one JSON line (rank 0).
-  roofline      the dominant kernels (TV-L1 inner iterations).  `achieved`/`frac` follow SURVEY.md section 8d:
-                64 algorithmic bytes per pixel-iteration / wall time the kernels run, measured live with HIP events
-                around every run of their launches.  Because the kernels fuse 10-16 iterations in registers, that figure
-                is NOT a bound they obey (it exceeds the HBM peak); it is repeated as `frac_algorithmic_64B`, and the
-                bounds they do obey are reported next to it: `hbm_measured` (PMC bytes of the committed profile of this
-                very tvl1.hip, or null) and `valu` (vector instructions per pixel-iteration from the committed
-                SQ counters against the issue capacity of 1024 SIMDs), plus `per_level` timings measured live.
-  roofline_cnn  the conv/FC stack: TFLOP/s of a CNN-only leg timed after the main region, against the MFMA peak.
+  roofline      the dominant kernels (TV-L1 inner iterations), against the bound they obey: fp32 VECTOR arithmetic.
+                `achieved` = pixel-iterations x 55 FLOP (one S6 pixel-iteration counted from the specification, DESIGN.md
+                section 3: every fmaf = 2) / wall time the kernels run (HIP events around every run of their launches, union
+                over the streams), `peak` = 157.3 TFLOP/s, `frac` <= 1 -- all measured live.  Flat scalars next to it:
+                `frac_valu_needed` (the 59 vector instructions per 128-pixel level-row the arithmetic needs against the issue
+                capacity of 1024 SIMDs, live), `frac_valu_issued` / `frac_valu_busy` / `frac_hbm_measured` / `traffic` (PMC
+                counters of the committed profile of this very tvl1.hip and bench configuration, or null),
+                `algorithmic_64B_x_hbm_peak` (SURVEY.md section 8d's 64 B per pixel-iteration over the HBM peak: > 1 because
+                the kernels fuse 10-16 iterations in registers -- a byte model they do not execute, not an efficiency) and
+                `ns_per_kpx_iter_l0..4` (per pyramid level, live).
+  tvl1_hd       BASELINE config 3 after the timed region: TV-L1 only, 16 pairs 1280x720, 5 x 5 x 300, pairs/s and its fraction.
+  roofline_cnn / roofline_cnn_bf16   the conv/FC stack alone (fp32 parity configuration / BASELINE config 5's bf16 per GPU):
+                TFLOP/s of a CNN-only leg timed after the main region, against the dense MFMA peak of the dtype.
   cpu_baseline  the CPU oracle (C TV-L1 with OpenMP across pairs + torch-CPU VGG) on a bounded sample.
 """
 import argparse
@@ -40,6 +45,15 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense peaks (MI355X_MICROAR
 N_SIMD = 1024             # 256 CUs x 4 SIMDs
 BYTES_PER_PX_ITER = 64.0
 BYTES_PER_PX_WARP = 44.0
+# One S6 pixel-iteration counted from the specification (fmaf = 2, everything else 1):
+# rho 2 fmaf (4) + threshold: multiply and clamp (3) + v 2 fmaf (4) + div p 2 x (x difference, y difference, add) (6)
+# + u' 2 fmaf (4) + forward differences of u' (4) + |grad u'|^2 + 2^-100: 2 fmaf per component (8) + 2 square roots (2)
+# + d = 1 + tau/theta sqrt: 2 fmaf (4) + one division and three multiplies for the two reciprocals (4)
+# + p' = (p + tau/theta grad u') r: 4 x (fmaf + multiply) (12)
+FLOP_PER_PX_ITER = 55.0
+VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak (MI355X_MICROARCH.md)
+VALU_INSTR_PER_PX_ITER_MIN = 59.0 / 128.0  # the row pipeline's steady loop: 59 vector instructions per 128-pixel level-row
+CLOCK_GHZ_MAX = 2.4
 GFLOP_PER_CLIP = 62.852   # two VGG-16 streams, SURVEY.md section 2a / 8d
 BATCH = 32
 TVL1_SRC = os.path.join(ROOT, "video_analytics_amd", "csrc", "tvl1.hip")
@@ -66,41 +80,44 @@ def committed_profile(name):
     return None
 
 
-def pmc_blocks(cfg, busy_ms_per_step, px_iters_per_step, launches_per_step):
-    """`traffic`, `hbm_measured` and `valu` from the committed PMC passes of this same command (separate rocprofv3
-    runs: FETCH_SIZE, WRITE_SIZE, SQ counters; FETCH_SIZE doubled per the gfx950 rule of MI355X_MICROARCH.md)."""
-    traffic = hbm = valu = None
+def profile_key(config):
+    """What a committed counter summary must agree on with the running benchmark, besides the tvl1.hip blob: the counters
+    of another arithmetic mode, stream count, block depth, tuning override or batch overlap are another kernel mix."""
+    return {k: config.get(k) for k in ("block_iters", "tvl1_math", "flow_streams", "batches_in_flight", "tvl1_params")}
+
+
+def pmc_blocks(config, busy_ms_per_step, px_iters_per_step, launches_per_step):
+    """Counter figures from the committed PMC passes of this same command (separate rocprofv3 runs: FETCH_SIZE, WRITE_SIZE,
+    SQ counters; FETCH_SIZE doubled per the gfx950 rule of MI355X_MICROARCH.md), or None where the committed summary was
+    not collected on this tvl1.hip AND this bench configuration."""
+    out = dict(traffic=None, hbm=None, valu=None)
+    want = profile_key(config)
     d = committed_profile("pmc_hbm_summary.json")
-    if d and int(d.get("flow_streams", -1)) == cfg["flow_streams"] and int(d.get("block_iters", -1)) == cfg["block_iters"]:
+    if d and d.get("bench_config") == want:
         f = sum(v["sum_KB"] for k, v in d["FETCH_SIZE"].items() if k.startswith("k_iter"))
         w = sum(v["sum_KB"] for k, v in d["WRITE_SIZE"].items() if k.startswith("k_iter"))
         n = sum(v["launches"] for k, v in d["FETCH_SIZE"].items() if k.startswith("k_iter"))
         steps = max(1, int(d.get("steps_profiled", 1)))
         bytes_per_step = (2.0 * f + w) * 1024.0 / steps
-        traffic = (2.0 * f + w) * 1024.0 / n
+        out["traffic"] = (2.0 * f + w) * 1024.0 / n
         gbs = bytes_per_step / (busy_ms_per_step * 1e-3) / 1e9
-        hbm = dict(GB_per_step=bytes_per_step / 1e9, GBps=gbs, frac_of_peak=gbs / HBM_PEAK_GBS,
-                   frac_of_algorithmic_bytes=bytes_per_step / (BYTES_PER_PX_ITER * px_iters_per_step), source=d["_path"])
+        out["hbm"] = dict(GB_per_step=bytes_per_step / 1e9, GBps=gbs, frac_of_peak=gbs / HBM_PEAK_GBS,
+                          frac_of_algorithmic_bytes=bytes_per_step / (BYTES_PER_PX_ITER * px_iters_per_step), source=d["_path"])
     v = committed_profile("pmc_valu_summary.json")
-    if v:
+    if v and v.get("bench_config") == want:
         steps = max(1, int(v.get("steps_profiled", 1)))
         insts = sum(x["SQ_INSTS_VALU"] for k, x in v["kernels"].items() if k.startswith("k_iter")) / steps
         busy = sum(x["SQ_ACTIVE_INST_VALU"] for k, x in v["kernels"].items() if k.startswith("k_iter")) * 4.0 / steps  # quad-cycles
-        clock_ghz = float(v.get("clock_ghz", 2.3))
+        clock_ghz = float(v.get("clock_ghz", CLOCK_GHZ_MAX))
         cap = N_SIMD * clock_ghz * 1e9 / 4.0  # wave-instructions per second the chip can issue (one per SIMD per 4 cycles)
-        # the least the arithmetic needs: 59 vector instructions per level-row of 128 pixels in the row pipeline's steady
-        # loop (2 pixels per lane, packed math; DESIGN.md section 5) = 0.461 wave-instructions per pixel-iteration
-        min_instr = 59.0 / 128.0
-        valu = dict(wave_instr_per_px_iter=insts / px_iters_per_step, wave_instr_per_step=insts,
-                    wave_instr_per_px_iter_min=min_instr,
-                    frac_min_work=min_instr * px_iters_per_step / cap / (busy_ms_per_step * 1e-3),
-                    issue_capacity_G_per_s=cap / 1e9, clock_ghz=clock_ghz,
-                    frac_useful=insts / cap / (busy_ms_per_step * 1e-3),
-                    frac_busy=busy / (N_SIMD * clock_ghz * 1e9) / (busy_ms_per_step * 1e-3),
-                    per_kernel={k: x["SQ_INSTS_VALU"] / max(x["px_iters"], 1.0) for k, x in v["kernels"].items()
-                                if k.startswith("k_iter") and x.get("px_iters")},
-                    source=v["_path"])
-    return traffic, hbm, valu
+        out["valu"] = dict(wave_instr_per_px_iter=insts / px_iters_per_step, wave_instr_per_step=insts,
+                           issue_capacity_G_per_s=cap / 1e9, clock_ghz=clock_ghz,
+                           frac_issued=insts / cap / (busy_ms_per_step * 1e-3),
+                           frac_busy=busy / (N_SIMD * clock_ghz * 1e9) / (busy_ms_per_step * 1e-3),
+                           per_kernel={k: x["SQ_INSTS_VALU"] / max(x["px_iters"], 1.0) for k, x in v["kernels"].items()
+                                       if k.startswith("k_iter") and x.get("px_iters")},
+                           source=v["_path"])
+    return out
 
 
 def cpu_baseline(n_pairs_per_core, tv_kw, repeats=3):
@@ -150,6 +167,57 @@ def cpu_baseline(n_pairs_per_core, tv_kw, repeats=3):
                 sample="%d TV-L1 pairs 224x224 5x5x300 fixed iterations in the C oracle (%d per thread, OpenMP over pairs), "
                        "median of %d runs; two VGG-16 forwards of %d clips on torch-CPU fp32, median of %d; "
                        "value = 1 / (10 / pairs_per_s + 1 / cnn_clips_per_s)" % (n_pairs, n_pairs_per_core, repeats, cores, repeats))
+
+
+def cnn_leg(pipe, rgb, stack, dtype, reps=5):
+    """Both VGG-16 streams of 32 clips on a precomputed flow volume, `reps` batches after one warm-up: TFLOP/s of the whole
+    leg (layout, classifier and launch gaps included) against the dense MFMA peak of the dtype."""
+    import torch
+    pipe.run_batch(rgb, flow_stack=stack)
+    torch.cuda.synchronize()
+    tc = time.perf_counter()
+    for _ in range(reps):
+        pipe.submit(rgb, flow_stack=stack)
+    pipe.wait()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - tc) / reps * 1e3
+    tf = BATCH * GFLOP_PER_CLIP / ms  # GFLOP / ms = TFLOP/s
+    peak = MFMA_PEAK_TFLOPS[dtype]
+    return dict(bound="mfma", kernel="k_conv3x3_* + k_fc_* (both VGG-16 streams, 32 clips)", achieved=tf, peak=peak,
+                unit="TFLOP/s", frac=tf / peak, ms_per_batch=ms, gflop_per_clip=GFLOP_PER_CLIP, dtype=dtype,
+                note="whole CNN leg incl. layout, FC and launch gaps; counter-based MFMA utilisation per layer: profiles/")
+
+
+def tvl1_hd_leg(args, dev, n_pairs=16, reps=2):
+    """BASELINE config 3: TV-L1 only on 1280x720 pairs (same texture / warp generator, seed 3; 16 pairs resident; fixed
+    5 x 5 x 300 schedule), timed after the main region.  pairs/s, and the same fp32-vector fraction as `roofline`."""
+    import torch
+    from video_analytics_amd import _ffi, synth
+    from video_analytics_amd import flow as vflow
+    _, gray, _ = synth.synth_clips(2, seed=3, H=720, W=1280, n_gray=2)
+    fr = gray.to(dev).repeat(n_pairs // 2, 1, 1, 1)  # [16, 2, 720, 1280]: 16 pairs resident
+    prm = _ffi.default_tvl1_params(epsilon=0.0, iters=300, warps=5, nscales=5, fast_math=int(args.tvl1_math == "fast"))
+    out = torch.empty((n_pairs, 2, 720, 1280), dtype=torch.float32, device=dev)
+    vflow.tvl1_flow(fr, prm, out=out)
+    torch.cuda.synchronize()
+    vflow.profile_enable(True, dev.index)
+    vflow.profile_read(reset=True, device=dev.index)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        vflow.tvl1_flow(fr, prm, out=out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    p = vflow.profile_read(reset=True, device=dev.index)
+    vflow.profile_levels(16, reset=True, device=dev.index)
+    vflow.profile_enable(False, dev.index)
+    busy_s = (p["union_ms"] if p["union_ms"] > 0 else p["ms"]) * 1e-3
+    tf = FLOP_PER_PX_ITER * p["px_iters"] / busy_s / 1e12 if busy_s > 0 else None
+    return dict(workload="TV-L1 only, %d pairs 1280x720, 5 scales x 5 warps x 300 iterations (fixed), exact arithmetic" % n_pairs
+                if args.tvl1_math == "exact" else "TV-L1 only, %d pairs 1280x720, 5x5x300, fast_math" % n_pairs,
+                pairs_per_s=n_pairs / dt, ms_per_pair=dt / n_pairs * 1e3, bound="valu_fp32", achieved=tf, peak=VALU_PEAK_TFLOPS,
+                unit="TFLOP/s", frac=tf / VALU_PEAK_TFLOPS if tf else None,
+                gpx_iters_per_s=p["px_iters"] / busy_s / 1e9 if busy_s > 0 else None,
+                kernel_ms_per_pair=busy_s * 1e3 / reps / n_pairs, finite=bool(torch.isfinite(out).all().item()))
 
 
 def main():
@@ -255,49 +323,59 @@ def main():
     if rank == 0:
         clips = world * K * BATCH
         value = clips / elapsed
-        cfg = dict(block_iters=args.block_iters, flow_streams=args.flow_streams)
+        config = {"workload": "two-stream 224x224, 10-frame TV-L1 flow stack (5 scales x 5 warps x 300 its, fixed), "
+                              "VGG-16 spatial+temporal, batch=32 per GPU" + (" [CNN only: --no-flow]" if args.no_flow else ""),
+                  "global_batch": world * BATCH, "block_iters": args.block_iters, "tvl1_math": args.tvl1_math,
+                  "flow_streams": args.flow_streams, "batches_in_flight": 2 if args.pipelined else 1,
+                  "tvl1_params": args.tvl1_params, "tvl1_hip_blob": git_blob_hash(TVL1_SRC),
+                  "parallelism": "clips sharded x%d" % world, "finite": finite}
         roof = None
         if prof["launches"] > 0 and prof["ms"] > 0:
-            # `achieved`: algorithmic bytes of all inner-iteration launches / wall time during which they run
-            # (the union of the HIP-event intervals: with --flow-streams > 1 launches of different
-            # streams overlap).  `avg_launch_us` is the plain per-launch average (sum of per-stream
-            # kernel time / launches) that rocprofv3 --stats reports for the kernel.
-            alg_bytes = BYTES_PER_PX_ITER * prof["px_iters"]
+            # wall time during which the inner-iteration kernels run: the union of the HIP-event intervals (with
+            # --flow-streams > 1 launches of different streams overlap); everything below is per step of THIS run
             busy_ms = prof["union_ms"] if prof["union_ms"] > 0 else prof["ms"]
-            ach = alg_bytes / (busy_ms * 1e-3) / 1e9
-            traffic, hbm, valu = pmc_blocks(cfg, busy_ms / max(K, 1), prof["px_iters"] / max(K, 1), prof["launches"] / max(K, 1))
+            busy_s = busy_ms * 1e-3
+            tflops = FLOP_PER_PX_ITER * prof["px_iters"] / busy_s / 1e12
+            alg_gbs = BYTES_PER_PX_ITER * prof["px_iters"] / busy_s / 1e9
+            pmc = pmc_blocks(config, busy_ms / max(K, 1), prof["px_iters"] / max(K, 1), prof["launches"] / max(K, 1))
+            hbm, valu = pmc["hbm"], pmc["valu"]
             sizes = vflow.pyramid_sizes(224, 224, params)
             per_level = [dict(level=s, w=sizes[s][0], h=sizes[s][1], ms_per_step=l["ms"] / max(K, 1),
                               px_iters_per_step=l["px_iters"] / max(K, 1), launches_per_step=l["launches"] / max(K, 1),
                               ns_per_kpx_iter=(l["ms"] * 1e6) / (l["px_iters"] / 1e3) if l["px_iters"] else None)
                          for s, l in enumerate(levels[:len(sizes)])]
-            roof = dict(bound="hbm", kernel="k_iter_stream + k_iter_tile (TV-L1 inner iterations)", achieved=ach, peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=ach / HBM_PEAK_GBS, frac_algorithmic_64B=ach / HBM_PEAK_GBS,
-                        note="frac is the SURVEY 8d figure (64 algorithmic B per pixel-iteration); the kernels fuse 10-16 "
-                             "iterations in registers, so it is not an efficiency: see hbm_measured and valu",
-                        traffic=traffic, hbm_measured=hbm, valu=valu, per_level=per_level,
+            roof = dict(bound="valu_fp32", kernel="k_iter_stream + k_iter_tile (TV-L1 inner iterations)",
+                        achieved=tflops, peak=VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=tflops / VALU_PEAK_TFLOPS,
+                        flop_per_px_iter=FLOP_PER_PX_ITER, px_iters_per_step=prof["px_iters"] / max(K, 1),
+                        gpx_iters_per_s=prof["px_iters"] / busy_s / 1e9, kernel_ms_per_step=busy_ms / max(K, 1),
                         launches=int(prof["launches"]), avg_launch_us=prof["ms"] * 1e3 / prof["launches"],
-                        alg_bytes_per_launch=alg_bytes / prof["launches"], kernel_ms_per_step=busy_ms / max(K, 1),
-                        achieved_per_launch=alg_bytes / (prof["ms"] * 1e-3) / 1e9, concurrent_streams=args.flow_streams)
-        # CNN-only leg (outside the timed region): both VGG-16 streams on precomputed flow volumes
-        cnn = None
+                        concurrent_streams=args.flow_streams,
+                        # the instructions the arithmetic needs against the chip's issue capacity (one per SIMD per 4 cycles)
+                        frac_valu_needed=VALU_INSTR_PER_PX_ITER_MIN * prof["px_iters"] / (N_SIMD * CLOCK_GHZ_MAX * 1e9 / 4.0) / busy_s,
+                        frac_valu_issued=valu["frac_issued"] if valu else None, frac_valu_busy=valu["frac_busy"] if valu else None,
+                        valu_instr_per_px_iter=valu["wave_instr_per_px_iter"] if valu else None,
+                        frac_hbm_measured=hbm["frac_of_peak"] if hbm else None, hbm_GBps_measured=hbm["GBps"] if hbm else None,
+                        traffic=pmc["traffic"],
+                        algorithmic_64B_GBps=alg_gbs, algorithmic_64B_x_hbm_peak=alg_gbs / HBM_PEAK_GBS,
+                        note="bound = fp32 vector arithmetic (55 FLOP per S6 pixel-iteration over 157.3 TFLOP/s); the 64 B figure of "
+                             "SURVEY 8d is a byte model the kernels do not execute (they fuse 10-16 iterations in registers)",
+                        hbm_measured=hbm, valu=valu, per_level=per_level)
+            for l in per_level:
+                roof["ns_per_kpx_iter_l%d" % l["level"]] = l["ns_per_kpx_iter"]
+        hd = cnn = cnn_bf16 = None
         if world == 1:
+            hd = tvl1_hd_leg(args, dev)
+            # CNN-only legs (outside the timed region): both VGG-16 streams on precomputed flow volumes
             # (a synthetic flow volume: the CNN's time does not depend on the values, and no TV-L1 work is added to the run)
             st2 = stack if stack is not None else torch.from_numpy(
                 synth.hash_uniform(5, 5, BATCH * 20 * 224 * 224).reshape(BATCH, 20, 224, 224) * 4.0 - 2.0).to(dev)
-            pipe.run_batch(rgb, flow_stack=st2)
-            torch.cuda.synchronize()
-            tc = time.perf_counter()
-            for _ in range(5):
-                pipe.submit(rgb, flow_stack=st2)
-            pipe.wait()
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - tc) / 5 * 1e3
-            tf = BATCH * GFLOP_PER_CLIP / ms  # GFLOP / ms = TFLOP/s
-            peak = MFMA_PEAK_TFLOPS[args.cnn_dtype]
-            cnn = dict(bound="mfma", kernel="k_conv3x3_* + k_fc_* (both VGG-16 streams, 32 clips)", achieved=tf, peak=peak,
-                       unit="TFLOP/s", frac=tf / peak, ms_per_batch=ms, gflop_per_clip=GFLOP_PER_CLIP, dtype=args.cnn_dtype,
-                       note="whole CNN leg incl. layout, FC and launch gaps; counter-based MFMA utilisation per layer: profiles/")
+            cnn = cnn_leg(pipe, rgb, st2, args.cnn_dtype)
+            pipe.close()
+            other = "bf16" if args.cnn_dtype == "f32" else "f32"
+            pipe2 = pipeline.TwoStreamPipeline(device=local_rank, tvl1_params=params, flow_streams=args.flow_streams, cnn_dtype=other)
+            leg2 = cnn_leg(pipe2, rgb, st2, other)
+            pipe2.close()
+            cnn, cnn_bf16 = (cnn, leg2) if args.cnn_dtype == "f32" else (leg2, cnn)
         cpu = None
         if world == 1 and args.cpu_pairs_per_core > 0:
             cpu = cpu_baseline(args.cpu_pairs_per_core, tv_kw)
@@ -306,15 +384,11 @@ def main():
             "value": value, "unit": "clips/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed / max(K, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.cnn_dtype == "f32" else "bf16 (CNN) / f32 (TV-L1)", "data": "synthetic",
-            "config": {"workload": "two-stream 224x224, 10-frame TV-L1 flow stack (5 scales x 5 warps x 300 its, fixed), "
-                                   "VGG-16 spatial+temporal, batch=32 per GPU" + (" [CNN only: --no-flow]" if args.no_flow else ""),
-                       "global_batch": world * BATCH, "block_iters": args.block_iters, "tvl1_math": args.tvl1_math,
-                       "flow_streams": args.flow_streams, "batches_in_flight": 2 if args.pipelined else 1,
-                       "tvl1_hip_blob": git_blob_hash(TVL1_SRC), "parallelism": "clips sharded x%d" % world, "finite": finite},
-            "roofline": roof, "roofline_cnn": cnn, "cpu_baseline": cpu,
+            "config": config, "roofline": roof, "tvl1_hd": hd, "roofline_cnn": cnn, "roofline_cnn_bf16": cnn_bf16, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    pipe.close()
+    if not (rank == 0 and world == 1):
+        pipe.close()
     if world > 1:
         import torch.distributed as td
         td.destroy_process_group()

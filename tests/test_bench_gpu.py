@@ -46,8 +46,20 @@ def test_bench_single_gpu_line_has_the_contract_fields():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d
     roof = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_valu_needed", "frac_valu_issued", "frac_hbm_measured",
+              "algorithmic_64B_x_hbm_peak", "ns_per_kpx_iter_l0", "ns_per_kpx_iter_l4"):
         assert k in roof
+    # a bound the kernels obey: fp32 vector arithmetic, 55 FLOP per S6 pixel-iteration, measured live
+    assert roof["bound"] == "valu_fp32" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3
+    assert 0.0 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert abs(roof["achieved"] - 55.0 * roof["px_iters_per_step"] / (roof["kernel_ms_per_step"] * 1e-3) / 1e12) < 1e-6 * roof["achieved"]
+    assert abs(roof["px_iters_per_step"] - 320 * 1500 * sum(n * n for n in (224, 179, 143, 114, 91))) < 1.0
+    assert 0.0 < roof["frac_valu_needed"] <= 1.0
+    # BASELINE configs 3 and 5 in the same line: TV-L1 only at 1280x720, the bf16 conv stack per GPU
+    hd = d["tvl1_hd"]
+    assert hd["pairs_per_s"] > 10 and 0.0 < hd["frac"] <= 1.0 and hd["finite"]
+    for key, dt in (("roofline_cnn", "f32"), ("roofline_cnn_bf16", "bf16")):
+        assert d[key]["dtype"] == dt and d[key]["bound"] == "mfma" and 0.0 < d[key]["frac"] <= 1.0
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32"
 
 

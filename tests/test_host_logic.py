@@ -164,13 +164,18 @@ def test_combine_descriptors_join_order_and_layout(tmp_path):
 
 def test_datasets_read_the_reference_directory_layout(tmp_path):
     from PIL import Image
+    from video_analytics_amd.parameters import NORM_MEANS_TF, NORM_STDS_TF
     from video_analytics_amd.spatialModel import SpatialDataset
     from video_analytics_amd.temporalModel import TemporalDataset
     lst = tmp_path / "list.txt"
     lst.write_text("Archery/v_Archery_g01_c01.avi\nBiking/v_Biking_g02_c03.avi\n")
     lab = tmp_path / "classInd.txt"
     lab.write_text("1 Archery\n2 Biking\n")
-    rng = np.random.default_rng(0)
+
+    def flow_base(ax, i):  # every flow image has its own gray level: the file a channel came from can be read off it
+        return (8 if ax == "x" else 128) + 8 * i
+
+    ramp = (np.arange(320) // 32).astype(np.uint8)  # + a step pattern along x that shows where an image was cropped / flipped
     for cat, vid in (("Archery", "v_Archery_g01_c01"), ("Biking", "v_Biking_g02_c03")):
         fd = tmp_path / "frames" / cat / vid
         fd.mkdir(parents=True)
@@ -180,16 +185,43 @@ def test_datasets_read_the_reference_directory_layout(tmp_path):
         wd.mkdir(parents=True)
         for i in range(1, 14):
             for ax in ("x", "y"):
-                Image.fromarray(rng.integers(0, 255, (240, 320), dtype=np.uint8), mode="L").save(str(wd / ("flow_%s_%04d.jpg" % (ax, i))))
+                img = np.broadcast_to(flow_base(ax, i) + ramp[None, :], (240, 320)).astype(np.uint8)
+                Image.fromarray(img, mode="L").save(str(wd / ("flow_%s_%04d.png" % (ax, i))), format="PNG")
+                os.rename(str(wd / ("flow_%s_%04d.png" % (ax, i))), str(wd / ("flow_%s_%04d.jpg" % (ax, i))))  # lossless content, reference name
     tf = U.getTransforms()
     random.seed(0)
     ds = SpatialDataset(str(lst), str(tmp_path / "frames"), tf, mode="test", actionLabelLoc=str(lab))
     assert len(ds) == 2
     x, label, name = ds[1]
     assert x.shape == (3, 224, 224) and label == 2 and name == "v_Biking_g02_c03"
-    dt = TemporalDataset(str(lst), str(tmp_path / "flow"), tf, flowSampleSize=10, mode="test", actionLabelLoc=str(lab))
-    v, label, name = dt[0]
-    assert v.shape == (20, 224, 224) and label == 1 and name == "v_Archery_g01_c01"
+    # --- TemporalDataset (Sheet03/temporalModel.py:67-92): which files, in which order, one crop / flip per image
+    opened = []
+
+    class Recording(object):  # the reference's transform chain, noting every image it is handed
+        def __call__(self, img):
+            opened.append(os.path.basename(img.filename))
+            return tf(img)
+
+    dt = TemporalDataset(str(lst), str(tmp_path / "flow"), Recording(), flowSampleSize=10, mode="test", actionLabelLoc=str(lab))
+    for seed in (0, 1, 2, 3):
+        random.seed(seed)
+        start = random.randint(1, 13 - 10)  # the dataset's FIRST draw: start in [1, nFlows - L] = [1, 3]
+        random.seed(seed)
+        del opened[:]
+        v, label, name = dt[0]
+        assert v.shape == (20, 224, 224) and label == 1 and name == "v_Archery_g01_c01"
+        want = [("flow_%s_%04d.jpg" % (ax, start + k)) for k in range(10) for ax in ("x", "y")]
+        assert opened == want  # x_s, y_s, x_{s+1}, y_{s+1}, ...: exactly 2L files, none beyond start + L - 1
+        q = v * NORM_STDS_TF[0] + NORM_MEANS_TF[0]  # undo the single-channel Normalize -> q / 255
+        profiles = set()
+        for k in range(10):
+            for j, ax in enumerate(("x", "y")):
+                row = (q[2 * k + j, 0] * 255.0).round().to(torch.int64) - flow_base(ax, start + k)
+                assert 0 <= int(row.min()) and int(row.max()) <= 9, (k, ax)  # channel 2k + j IS flow_<ax>_<start + k>
+                assert torch.equal((q[2 * k + j] * 255.0).round().to(torch.int64) - flow_base(ax, start + k),
+                                   row[None, :].expand(224, 224))  # (columns only: the step pattern)
+                profiles.add(tuple(row.tolist()))
+        assert len(profiles) >= 8  # 20 independent (left offset, flip) draws, not one crop for the whole volume (quirk 2)
     with pytest.raises(ValueError):
         SpatialDataset(str(lst), str(tmp_path / "frames"), tf, mode="test")  # no label file: Sheet03/spatialModel.py:46
 

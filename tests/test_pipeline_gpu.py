@@ -280,3 +280,78 @@ def test_config1_demoTest_clip_through_dataset_and_validate(tmp_path):
     rows = open(p).read().strip().split("\n")
     assert len(rows) == 3 and rows[0].startswith("v_ApplyEyeMakeup_g01_c01,1,") and len(rows[0].split(",")) == 258
     net.model.close()
+
+
+def test_temporal_file_path_gpu_flow_to_jpegs_to_dataset_to_validate(tmp_path):
+    """SURVEY 8f row 1 end to end, the temporal twin of the config-1 test: synthetic 320x240 gray frames -> ``va_tvl1_flow``
+    on the GPU -> ``utils.saveFlowImages`` into the reference's layout ``<root>/<category>/<video>/flow_{x,y}_%04d.jpg``
+    (1-based, 8-bit single-channel JPEGs: Sheet03/temporalModel.py:76-81, parameters.py:27,38-39) -> the file-backed
+    ``TemporalDataset`` (random start in [1, nFlows - L], x/y interleave, one random crop and flip PER IMAGE, ToTensor,
+    single-channel Normalize: :67-92) -> ``DataLoader`` -> ``TemporalNetwork.validate()`` (:226-260) on the GPU, against
+    the torch-CPU oracle evaluated on the very tensors the dataset produced.  The random draws are replayed by re-seeding
+    Python's global generator; what the files hold is checked against the flow the GPU produced."""
+    import random
+    from PIL import Image
+    from oracle import vgg_oracle
+    from video_analytics_amd import flow as vflow, synth, utils as U
+    from video_analytics_amd.temporalModel import TemporalDataset, TemporalNetwork
+    lines = open(os.path.join(GOLD, "demoTest.txt")).readlines()[:3]
+    lst = tmp_path / "demoTest_head.txt"
+    lst.write_text("".join(lines))
+    (tmp_path / "classInd.txt").write_text("1 ApplyEyeMakeup\n2 ApplyLipstick\n3 Archery\n")
+    L, n_frames = 10, (13, 12, 14)  # 12, 11, 13 flow pairs per video: start in [1, 2], [1, 1], [1, 3]
+    flows = {}
+    for k, line in enumerate(lines):
+        _, videoName, _, category, _, _ = U.videoInfo(line, "test")
+        # one clip of n frames at UCF-101's 320x240 (the texture / warp generator of the benchmark)
+        _, gray, _ = synth.synth_clips(1, seed=40 + k, H=240, W=320, n_gray=n_frames[k])
+        fl = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=20, warps=2, nscales=3)  # [n - 1, 2, 240, 320]
+        assert fl.shape == (n_frames[k] - 1, 2, 240, 320) and bool(torch.isfinite(fl).all())
+        fd = tmp_path / "flows" / category / videoName
+        assert U.saveFlowImages(fl, str(fd)) == 2 * (n_frames[k] - 1)
+        flows[videoName] = U.flowToImages(fl)  # what the files should hold, up to JPEG
+        names = sorted(os.listdir(str(fd)))
+        assert names[0] == "flow_x_0001.jpg" and names[-1] == "flow_y_%04d.jpg" % (n_frames[k] - 1) and len(names) == 2 * (n_frames[k] - 1)
+        img = Image.open(str(fd / "flow_y_0003.jpg"))
+        assert img.mode == "L" and img.size == (320, 240)
+        err = np.abs(np.asarray(img, dtype=np.int32) - flows[videoName][2, 1].astype(np.int32))
+        assert err.mean() < 1.5 and err.max() <= 24  # JPEG quality 95 of a smooth field
+    ds = TemporalDataset(str(lst), str(tmp_path / "flows"), U.getTransforms(), flowSampleSize=L, mode="test",
+                         actionLabelLoc=str(tmp_path / "classInd.txt"))
+    loader = U.getDataLoader(ds, batchSize=2, nWorkers=0, shuffle=False)
+    random.seed(2218)
+    batches = [(d.clone(), l.clone(), list(n)) for d, l, n in loader]
+    assert [n for _, _, ns in batches for n in ns] == ["v_ApplyEyeMakeup_g01_c01", "v_ApplyEyeMakeup_g01_c02", "v_ApplyEyeMakeup_g01_c03"]
+    assert [int(v) for _, l, _ in batches for v in l] == [1, 1, 1]
+    for d, _, _ in batches:
+        assert d.shape[1:] == (20, 224, 224) and d.dtype == torch.float32
+        # (q / 255 - 0.485) / 0.229 with q in [0, 255] (the single-channel Normalize rule): the flow is small against the
+        # bound of 20 px, so every value sits near the image of q = 127.5
+        assert float(d.min()) >= (0.0 - 0.485) / 0.229 - 1e-6 and float(d.max()) <= (1.0 - 0.485) / 0.229 + 1e-6
+        assert abs(float(d.mean()) - (0.5 - 0.485) / 0.229) < 0.2
+    w = synth.synth_vgg16_weights(c_in=20, seed=2)
+    w["conv_w"][0] = vgg_oracle.copy_first_layer(w["conv_w"][0], 20)
+    loss_r, corr_r, desc_r = 0.0, 0, {}
+    for d, l, ns in batches:
+        _, desc, logits = vgg_oracle.forward(d, w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"])
+        lb, cb = vgg_oracle.validate_batch(logits, l)
+        loss_r += float(lb)
+        corr_r += cb
+        for i, n in enumerate(ns):
+            desc_r[n] = desc[i]
+    net = TemporalNetwork(101, L, 1, 0.1, 0.9, 256, None, loader, [10, 20], None, gpu=True,
+                          weights={k: [t.clone() for t in v] for k, v in w.items()})
+    random.seed(2218)  # the same start / crop / flip draws again
+    acc, loss = net.validate()
+    assert acc == corr_r / 3
+    assert abs(float(loss) - loss_r) < TOL
+    assert list(net.testDict.keys()) == list(desc_r.keys())
+    for n, ref in desc_r.items():
+        meter, label = net.testDict[n]
+        assert int(label) == 1 and meter.count == 1
+        assert float((meter.avg - ref).abs().max()) < TOL
+    p = str(tmp_path / "temporal_test.csv")
+    U.saveVideoDescriptors(net.testDict, p, True)
+    rows = open(p).read().strip().split("\n")
+    assert len(rows) == 3 and rows[0].startswith("v_ApplyEyeMakeup_g01_c01,1,") and len(rows[0].split(",")) == 258
+    net.model.close()

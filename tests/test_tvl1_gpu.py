@@ -106,6 +106,21 @@ def test_streaming_kernel_pixels_per_lane_bit_exact(oracle_tvl1, ppl, H, W, nch)
         assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("waves", [5, 6])
+@pytest.mark.parametrize("H,W,nch", [(224, 224, 0), (224, 224, 3), (100, 64, 3), (129, 225, 2), (57, 131, 1), (179, 179, 2), (114, 114, 1),
+                                     (48, 64, 0), (17, 19, 0), (33, 130, 1)])
+def test_streaming_kernel_two_chains_per_wave_bit_exact(oracle_tvl1, waves, H, W, nch):
+    # stream_waves = 5 / 6: the levels of a wave are cut into TWO chains that are issued interleaved (the second chain takes
+    # its rows from a register latch one step later): one deep wave with 2 x 8 levels / two waves with 2 x 4 levels each.
+    # Iteration counts that do and do not fill the pipeline (16), passes that end in the first / second chain of the last
+    # wave (37 = 16 + 16 + 5; 29 = 16 + 13), chunks of rows, strips with halos, the smallest frames
+    gray = _frames(1, 3, H, W, seed=H + 5 * W)
+    for iters, warps, nscales in ((10, 1, 1), (37, 2, 3), (29, 1, 2), (48, 1, 1)):
+        ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=warps, nscales=nscales, tile_mask=1 << 8,
+                             stream_chunks=nch, stream_waves=waves)
+        assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
 @pytest.mark.parametrize("H,W,nch", [(224, 224, 0), (100, 64, 3), (129, 225, 2), (57, 131, 1), (179, 179, 2)])
 def test_streaming_kernel_one_deep_wave_bit_exact(oracle_tvl1, H, W, nch):
     _needs_experiments()
@@ -205,6 +220,18 @@ def test_row_pipeline_full_schedule_and_mixed_levels(oracle_tvl1):
     for rows, stream in ((0b10101, 0b01000), (0b01010, 0b00001), (0b11111, 0)):
         out = vflow.tvl1_flow(gray.cuda(), epsilon=0.0, iters=25, warps=2, rows_levels=rows, stream_levels=stream).cpu().numpy()
         assert np.array_equal(out, ref), "rows %d stream %d: max abs diff %g" % (rows, stream, np.abs(out - ref).max())
+
+
+@pytest.mark.parametrize("H,W,kw", [(100, 16, dict(rows_levels=0b10)), (120, 20, dict(rows_levels=0b10)),
+                                    (100, 16, dict(stream_ppl=3, stream_levels=0b10)), (120, 20, dict(stream_ppl=3, stream_levels=0b110))])
+def test_narrow_tall_frames_with_mixed_level_layouts(oracle_tvl1, H, W, kw):
+    """A coarser level can have the LARGER plane when only it gets the 12-float pitch of k_iter_rows / three pixels per lane
+    (16 x 100: pitch 16, plane 1600 at level 0; 13 x 80 at level 1: pitch 24, plane 1920): the shared state / constants
+    buffers are sized for the largest plane of the pyramid, not for level 0's."""
+    _needs_experiments()
+    gray = _frames(3, 3, H, W, seed=H * W)
+    ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=23, warps=2, nscales=3, **kw)
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 
 def test_streaming_kernel_fast_math_and_mixed_levels(oracle_tvl1):

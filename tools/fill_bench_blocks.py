@@ -16,17 +16,17 @@ import bench  # noqa: E402
 
 def main(path):
     d = json.load(open(path))
-    r, cfg, K = d["roofline"], d["config"], d["steps"]
-    px = sum(l["px_iters_per_step"] for l in r["per_level"])
-    traffic, hbm, valu = bench.pmc_blocks(dict(block_iters=cfg["block_iters"], flow_streams=cfg["flow_streams"]),
-                                          r["kernel_ms_per_step"], px, r["launches"] / K)
-    if traffic is None or valu is None:
-        raise SystemExit("the committed summaries are not stamped with this tvl1.hip: re-run tools/summarize_profiles.py")
-    r["traffic"], r["hbm_measured"], r["valu"] = traffic, hbm, valu
+    r, K = d["roofline"], d["steps"]
+    pmc = bench.pmc_blocks(d["config"], r["kernel_ms_per_step"], r["px_iters_per_step"], r["launches"] / K)
+    hbm, valu = pmc["hbm"], pmc["valu"]
+    if hbm is None or valu is None:
+        raise SystemExit("the committed summaries are not stamped with this tvl1.hip and bench configuration: re-run tools/summarize_profiles.py")
+    r.update(traffic=pmc["traffic"], hbm_measured=hbm, valu=valu, frac_valu_issued=valu["frac_issued"], frac_valu_busy=valu["frac_busy"],
+             valu_instr_per_px_iter=valu["wave_instr_per_px_iter"], frac_hbm_measured=hbm["frac_of_peak"], hbm_GBps_measured=hbm["GBps"])
     json.dump(d, open(path, "w"), indent=1)
-    print("hbm: %.1f GB/step, %.2f TB/s, %.2f of peak | valu: %.3f instr/px-it, useful %.2f, min %.2f, busy %.2f"
-          % (hbm["GB_per_step"], hbm["GBps"] / 1e3, hbm["frac_of_peak"], valu["wave_instr_per_px_iter"], valu["frac_useful"],
-             valu["frac_min_work"], valu["frac_busy"]))
+    print("hbm: %.1f GB/step, %.2f TB/s, %.2f of peak | valu: %.3f instr/px-it, issued %.2f, needed %.2f, busy %.2f"
+          % (hbm["GB_per_step"], hbm["GBps"] / 1e3, hbm["frac_of_peak"], valu["wave_instr_per_px_iter"], valu["frac_issued"],
+             r["frac_valu_needed"], valu["frac_busy"]))
 
 
 if __name__ == "__main__":

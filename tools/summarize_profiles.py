@@ -5,8 +5,9 @@
 expects under <prefix>/: trace/ (rocprofv3 --kernel-trace --stats), pmc_fetch/, pmc_write/ (--pmc FETCH_SIZE / WRITE_SIZE),
 pmc_sq/ (--pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace), each the -d target of one
 run of the SAME bench.py command, and bench.log / trace_bench.log / pmc_*_bench.log (bench.py's stdout of those runs).
-Every summary is stamped with the git blob hash of video_analytics_amd/csrc/tvl1.hip: bench.py reports a committed
-counter figure only while that hash equals the source it runs (otherwise `traffic`, `hbm_measured`, `valu` are null)."""
+Every summary is stamped with the git blob hash of video_analytics_amd/csrc/tvl1.hip and with the bench configuration
+of its own run (bench.profile_key: arithmetic mode, streams, block depth, tuning overrides, batches in flight): bench.py
+reports a committed counter figure only while both equal what it runs (otherwise the counter-derived keys are null)."""
 import collections
 import csv
 import glob
@@ -17,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import TVL1_SRC, git_blob_hash  # noqa: E402
+from bench import TVL1_SRC, git_blob_hash, profile_key  # noqa: E402
 
 
 def bench_line(path):
@@ -59,7 +60,7 @@ def main(prefix, out):
     cfg = bench_line(os.path.join(prefix, "bench.log"))["config"]
 
     # ---- HBM-side bytes per kernel
-    summ = {"tvl1_hip_blob": stamp, "block_iters": cfg.get("block_iters", 0), "flow_streams": cfg.get("flow_streams", 1),
+    summ = {"tvl1_hip_blob": stamp, "bench_config": profile_key(bench_line(os.path.join(prefix, "pmc_fetch_bench.log"))["config"]),
             "units": "KB (raw rocprofv3 counter values); gfx950: double FETCH_SIZE for coalesced wide loads"}
     for tag, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         agg = collections.defaultdict(lambda: [0, 0.0])
@@ -112,7 +113,7 @@ def main(prefix, out):
         # GRBM_GUI_ACTIVE / 8 / duration reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS): the
         # quotient is recorded as measured, the issue capacity is priced at no more than the 2.4 GHz maximum clock
         clk = (gui / 8.0 / tot / 1e9) if tot else 2.4
-        valu = {"tvl1_hip_blob": stamp, "steps_profiled": steps, "clock_ghz_gui_quotient": clk, "clock_ghz": min(clk, 2.4),
+        valu = {"tvl1_hip_blob": stamp, "bench_config": profile_key(line["config"]), "steps_profiled": steps, "clock_ghz_gui_quotient": clk, "clock_ghz": min(clk, 2.4),
                 "units": "SQ_INSTS_VALU: wave-instructions; SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES: quad-cycles; summed over the profiled run "
                          "(kernels are serialised under --pmc); px_iters: pixel-iterations of the kernel over the same run",
                 "kernels": {k: dict(SQ_INSTS_VALU=v.get("SQ_INSTS_VALU", 0.0), SQ_ACTIVE_INST_VALU=v.get("SQ_ACTIVE_INST_VALU", 0.0),

@@ -346,6 +346,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef VA_CHUNK
 #define VA_CHUNK 1
 #endif
+// TIMING BUILDS ONLY (wrong results; never set in a product build): bit set of parts of k_iter_stream's steady steps to
+// leave out, for the stall accounting of profiles/README.md (round 3): 1 = the global stores of the last wave, 2 = the
+// global loads of the first wave (the rows loaded before the loop are reused), 4 = the hand-over rows (no if_put / if_get),
+// 8 = the ring reads (the first row's constants are reused), 16 = the sched_barriers, 32 = the ring writes
+#ifndef VA_TIMING_SKIP
+#define VA_TIMING_SKIP 0
+#endif
 #ifndef VA_CHUNK_MB
 #define VA_CHUNK_MB 150.0
 #endif
@@ -854,6 +861,14 @@ struct StreamArgs {
 // KH-1 out of a double-buffered LDS row instead of HBM and carries them through levels KH .. 2KH-1, so that one pass
 // over the strip is worth K <= 2 KH iterations of HBM traffic; both waves share the ring of per-warp constants; one
 // workgroup barrier per step keeps them a step apart.
+// NCH chains per wave (round 3): the KH levels of a wave are cut into NCH chains of KC = KH / NCH consecutive levels.
+// Inside a chain level t + 1 consumes what level t emits in the SAME step (one long dependent sequence of ~16 operations
+// per level); from one chain to the next the row waits in registers for one step (a latch, 6 x PPL registers), exactly
+// like the hand-over between the two waves but inside one.  The chains of a step are therefore independent of each
+// other and are issued interleaved, level by level: the exact square-root / reciprocal sequences and the s_nop hazard
+// slots of one chain are covered by the other's arithmetic (tools/microbench_tvl1_chain.hip: 125 instead of 147 ns per
+// level-row on the bare arithmetic).  Every chain end costs one step of pipeline depth: global level g works at
+// pipeline position pos(g) = g + (chain ends before g), i.e. on row s - pos(g) of the strip at step s.
 // PPL pixels per lane: a strip is 64 * PPL columns wide (2: 128, the default; 3: 192, so that a 129..192-column level is
 // ONE well-filled strip without any x halo -- a tested option that measured no faster, see stream_ppl()).
 // SUBS = 4 (k_iter_stream4): a 512-thread workgroup runs FOUR jobs, job `sub` on the waves sub (first wave) and sub + 4
@@ -861,17 +876,35 @@ struct StreamArgs {
 // share one: while one of them waits for the other, the other has the SIMD to itself.  All eight waves meet at every
 // barrier, so every job of the workgroup runs `steps_pad` steps (a job with fewer only joins the barrier); `active` =
 // false: a padding job.
-template <int PPL, int KH, int NWV, bool FAST, int SUBS = 1>
+template <int KH, int NCH>
+struct StreamShape {
+    static_assert(KH % NCH == 0, "the levels of a wave are cut into chains of equal length");
+    static constexpr int KC = KH / NCH;      // levels per chain
+    static constexpr int SPAN = KH + NCH;    // pipeline positions a wave occupies (its levels + its chain ends)
+    static constexpr int lpos(int t) { return t + t / KC; }  // position of the wave's level t behind the wave's first level
+};
+// rows of per-warp constants the LDS ring holds: the oldest row a level reads at step s is s - (its pipeline position)
+template <int KH, int NWV, int NCH>
+constexpr int stream_ring_rows() { return NWV == 1 ? KH + NCH - 2 : NWV * (KH + NCH) - 2; }
+
+template <int PPL>
+struct StreamRow {  // the six state fields of one row of a strip
+    Row<PPL> u1, u2, p11, p12, p21, p22;
+};
+
+template <int PPL, int KH, int NWV, bool FAST, int SUBS = 1, int NCH = 1>
 __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, const int job, const int K,
                                            const float* __restrict__ sin_all, float* __restrict__ sout_all, const int sub = 0,
                                            const int role = -1, const bool active = true, const int steps_pad = 0)
 {
     typedef Row<PPL> R;
-    constexpr int NP = R::NP, NT = R::NT, SW = 64 * PPL;
-    // ring rows: NWV = 1: level t >= 1 reads row s - t, row s is written at the end of step s.  NWV = 2: the first
+    typedef StreamRow<PPL> SR;
+    typedef StreamShape<KH, NCH> SH;
+    constexpr int NP = R::NP, NT = R::NT, SW = 64 * PPL, KC = SH::KC;
+    // ring rows: NWV = 1: level t >= 1 reads row s - lpos(t), row s is written at the end of step s.  NWV = 2: the first
     // wave writes row s - 1 at the start of step s (after the barrier), the oldest row read in step s is
-    // s - (KH + 1) - (KH - 1) = s - 2 KH.
-    constexpr int NRING = NWV == 1 ? KH - 1 : NWV * KH;
+    // s - (NWV * SPAN - 2), whose slot is that of row s (written in step s + 1).
+    constexpr int NRING = stream_ring_rows<KH, NWV, NCH>() > 0 ? stream_ring_rows<KH, NWV, NCH>() : 1;
     __shared__ f2 ringP_[SUBS][NRING][kNF_RO][NP][64];
     __shared__ float ringT_[SUBS][NRING][kNF_RO][NT ? 64 : 1];
     __shared__ f2 ifaceP_[SUBS][NWV > 1 ? NWV - 1 : 1][2][kNF_STATE][NP][64];
@@ -955,176 +988,211 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
     auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int f, int y) -> R { return row_load<PPL>(r, loff, f * planeb + y * pitchb); };
     auto st = [&](const R& v, int f, int y) { row_store<PPL>(v, rs_out, loff, f * planeb + y * pitchb); };
 
-    // level K-1 (in the last wave) emits row b0-1 when row b0 (or the dummy row h) comes in; every wave boundary adds a step
-    const int nsteps = active ? b0 - ys + K + (NWV - 1) : 0;
+    // the last valid row b0 - 1 leaves the last ACTIVE level (K - 1) when row b0 (or the dummy row h) comes in, and then
+    // waits one step at every chain end on its way to the last wave's output: NWV * NCH - 1 of them
+    const int nsteps = active ? b0 - ys + K + (NWV * NCH - 1) : 0;
 
     auto run = [&](auto wave_tag) __attribute__((always_inline)) {
         constexpr int W = decltype(wave_tag)::value;
         constexpr bool FIRST = W == 0, LAST = W == NWV - 1;
-        constexpr int G0 = W * KH, LAG = W * (KH + 1);  // first level of this wave; steps it runs behind the first wave
+        constexpr int G0 = W * KH, LAG = W * SH::SPAN;  // first level of this wave; steps it runs behind the first wave
 
         R P11[KH], P12[KH], P21[KH], P22[KH], U1[KH], U2[KH];
 #pragma clang loop unroll(full)
         for (int t = 0; t < KH; ++t) P11[t] = P12[t] = P21[t] = P22[t] = U1[t] = U2[t] = zero;
+        SR latch[NCH > 1 ? NCH - 1 : 1];  // what chain c emitted in the previous step: chain c + 1's input of this one
+#pragma clang loop unroll(full)
+        for (int c = 0; c < (NCH > 1 ? NCH - 1 : 1); ++c) latch[c] = SR{zero, zero, zero, zero, zero, zero};
         R nst[kNF_STATE], nro[kNF_RO], rprev[kNF_RO] = {zero, zero, zero, zero};
 #pragma clang loop unroll(full)
         for (int f = 0; f < kNF_STATE; ++f) nst[f] = FIRST ? ld(rs_in, f, ys) : zero;
 #pragma clang loop unroll(full)
         for (int f = 0; f < kNF_RO; ++f) nro[f] = FIRST ? ld(rs_ro, f, ys) : zero;
 
+        // One level: phase A on the incoming row C (k_iter_tile's arithmetic, operation for operation), phase B on the
+        // row above it (whose lower neighbour is the row just computed); the level keeps the incoming p and the new u,
+        // and passes on (its old u, the new p) = the time-(t+1) values of the row above.
+        // MY1: the row the level holds is not the image's last one (my = 1): its y differences need no multiplier
+        // (x * 1 = x exactly; the straight-line steady-state steps use this form)
+        auto level = [&](int t, SR& c, const R& wx, const R& wy, const R& rc, const R& ig, const float my, auto my1_tag) __attribute__((always_inline)) {
+            constexpr bool MY1 = decltype(my1_tag)::value;
+            // (the difference across the lane boundary is a plain subtraction inside r_diff_*: the compiler folds the
+            // lane shift into it -- one v_subrev_f32_dpp instead of v_mov_b32_dpp + v_sub_f32)
+            const R dx11 = r_diff_back(c.p11), dx21 = r_diff_back(c.p21);
+            const R div1 = r_add(dx11, r_sub(c.p12, P12[t]));
+            const R div2 = r_add(dx21, r_sub(c.p22, P22[t]));
+            const R rho = r_fma(wy, c.u2, r_fma(wx, c.u1, rc));
+            const R tt = r_negmul(rho, ig);
+            const R fi = r_med3(tt, -l_t, l_t);
+            const R v1 = r_fma(fi, wx, c.u1);
+            const R v2 = r_fma(fi, wy, c.u2);
+            const R n1 = r_fma_s(theta, div1, v1);
+            const R n2 = r_fma_s(theta, div2, v2);
+            const R d1x = r_diff_fwd(U1[t]), d2x = r_diff_fwd(U2[t]);
+            const R u1x = r_mul(d1x, mx), u1y = MY1 ? r_sub(n1, U1[t]) : r_mul_s(r_sub(n1, U1[t]), my);
+            const R u2x = r_mul(d2x, mx), u2y = MY1 ? r_sub(n2, U2[t]) : r_mul_s(r_sub(n2, U2[t]), my);
+            const R s1 = r_fma(u1y, u1y, r_fma_c(u1x, u1x, kSqrtReg));
+            const R s2 = r_fma(u2y, u2y, r_fma_c(u2x, u2x, kSqrtReg));
+            const R d1 = r_fma_s(taut, r_sqrt<PPL, FAST>(s1), one);
+            const R d2 = r_fma_s(taut, r_sqrt<PPL, FAST>(s2), one);
+            R q1, q2;
+            if constexpr (FAST) {
+                q1 = r_rcp<PPL, true>(d1);
+                q2 = r_rcp<PPL, true>(d2);
+            } else {
+                const R rinv = r_rcp<PPL, false>(r_mul(d1, d2));
+                q1 = r_mul(d2, rinv);
+                q2 = r_mul(d1, rinv);
+            }
+            const R o11 = r_mul(r_fma_s(taut, u1x, P11[t]), q1);
+            const R o12 = r_mul(r_fma_s(taut, u1y, P12[t]), q1);
+            const R o21 = r_mul(r_fma_s(taut, u2x, P21[t]), q2);
+            const R o22 = r_mul(r_fma_s(taut, u2y, P22[t]), q2);
+            const R ou1 = U1[t], ou2 = U2[t];
+            P11[t] = c.p11;
+            P12[t] = c.p12;
+            P21[t] = c.p21;
+            P22[t] = c.p22;
+            U1[t] = n1;
+            U2[t] = n2;
+            c.u1 = ou1;
+            c.u2 = ou2;
+            c.p11 = o11;
+            c.p12 = o12;
+            c.p21 = o21;
+            c.p22 = o22;
+        };
+
         auto step = [&](const int s, auto steady_tag) __attribute__((always_inline)) {
             constexpr bool STEADY = decltype(steady_tag)::value;
             const int s0 = s % NRING;  // row s of the strip lives in ring slot s % NRING
-            R c_u1, c_u2, c_p11, c_p12, c_p21, c_p22;
+            SR cc[NCH];                // the row travelling through chain c in this step
             R r0[kNF_RO] = {zero, zero, zero, zero};
             if constexpr (FIRST) {
-                c_u1 = nst[0], c_u2 = nst[1], c_p11 = nst[2], c_p12 = nst[3], c_p21 = nst[4], c_p22 = nst[5];
+                cc[0] = SR{nst[0], nst[1], nst[2], nst[3], nst[4], nst[5]};
 #pragma clang loop unroll(full)
                 for (int f = 0; f < kNF_RO; ++f) r0[f] = nro[f];
                 // next row (beyond the last row of the strip: row ye - 1 again -- finite values nobody uses, or, at the
                 // image bottom, the dummy row h whose only consumer multiplies its difference by my = 0)
                 const int rn = d_min(ys + s + 1, ye - 1);
+                if (!(STEADY && (VA_TIMING_SKIP & 2))) {
 #pragma clang loop unroll(full)
-                for (int f = 0; f < kNF_STATE; ++f) nst[f] = ld(rs_in, f, rn);
+                    for (int f = 0; f < kNF_STATE; ++f) nst[f] = ld(rs_in, f, rn);
 #pragma clang loop unroll(full)
-                for (int f = 0; f < kNF_RO; ++f) nro[f] = ld(rs_ro, f, rn);
+                    for (int f = 0; f < kNF_RO; ++f) nro[f] = ld(rs_ro, f, rn);
+                }
                 if constexpr (NWV > 1) {  // the constants of row s - 1 go into the ring now that the barrier has passed
                     const int sl = s0 == 0 ? NRING - 1 : s0 - 1;
+                    if (!(STEADY && (VA_TIMING_SKIP & 32)))
 #pragma clang loop unroll(full)
-                    for (int f = 0; f < kNF_RO; ++f) ring_put(sl, f, rprev[f]);
+                        for (int f = 0; f < kNF_RO; ++f) ring_put(sl, f, rprev[f]);
                 }
-                __builtin_amdgcn_sched_barrier(0);  // the loads stay at the top of the step: a whole step hides their latency
+                if (!(VA_TIMING_SKIP & 16)) __builtin_amdgcn_sched_barrier(0);  // the loads stay at the top of the step: a whole step hides their latency
             } else {
                 const int bsel = (s + 1) & 1;  // what the wave before wrote in step s - 1
-                c_u1 = if_get(W - 1, bsel, 0);
-                c_u2 = if_get(W - 1, bsel, 1);
-                c_p11 = if_get(W - 1, bsel, 2);
-                c_p12 = if_get(W - 1, bsel, 3);
-                c_p21 = if_get(W - 1, bsel, 4);
-                c_p22 = if_get(W - 1, bsel, 5);
-            }
-            // One level: phase A on the incoming row C (k_iter_tile's arithmetic, operation for operation), phase B on the
-            // row above it (whose lower neighbour is the row just computed); the level keeps the incoming p and the new u,
-            // and passes on (its old u, the new p) = the time-(t+1) values of the row above.
-            // MY1: the row the level holds is not the image's last one (my = 1): its y differences need no multiplier
-            // (x * 1 = x exactly; the straight-line steady-state steps use this form)
-            auto level = [&](int t, const R& wx, const R& wy, const R& rc, const R& ig, const float my, auto my1_tag) __attribute__((always_inline)) {
-                constexpr bool MY1 = decltype(my1_tag)::value;
-                // (the difference across the lane boundary is a plain subtraction inside r_diff_*: the compiler folds the
-                // lane shift into it -- one v_subrev_f32_dpp instead of v_mov_b32_dpp + v_sub_f32)
-                const R dx11 = r_diff_back(c_p11), dx21 = r_diff_back(c_p21);
-                const R div1 = r_add(dx11, r_sub(c_p12, P12[t]));
-                const R div2 = r_add(dx21, r_sub(c_p22, P22[t]));
-                const R rho = r_fma(wy, c_u2, r_fma(wx, c_u1, rc));
-                const R tt = r_negmul(rho, ig);
-                const R fi = r_med3(tt, -l_t, l_t);
-                const R v1 = r_fma(fi, wx, c_u1);
-                const R v2 = r_fma(fi, wy, c_u2);
-                const R n1 = r_fma_s(theta, div1, v1);
-                const R n2 = r_fma_s(theta, div2, v2);
-                const R d1x = r_diff_fwd(U1[t]), d2x = r_diff_fwd(U2[t]);
-                const R u1x = r_mul(d1x, mx), u1y = MY1 ? r_sub(n1, U1[t]) : r_mul_s(r_sub(n1, U1[t]), my);
-                const R u2x = r_mul(d2x, mx), u2y = MY1 ? r_sub(n2, U2[t]) : r_mul_s(r_sub(n2, U2[t]), my);
-                const R s1 = r_fma(u1y, u1y, r_fma_c(u1x, u1x, kSqrtReg));
-                const R s2 = r_fma(u2y, u2y, r_fma_c(u2x, u2x, kSqrtReg));
-                const R d1 = r_fma_s(taut, r_sqrt<PPL, FAST>(s1), one);
-                const R d2 = r_fma_s(taut, r_sqrt<PPL, FAST>(s2), one);
-                R q1, q2;
-                if constexpr (FAST) {
-                    q1 = r_rcp<PPL, true>(d1);
-                    q2 = r_rcp<PPL, true>(d2);
+                if (STEADY && (VA_TIMING_SKIP & 4)) {
+                    cc[0] = SR{U1[0], U2[0], P11[0], P12[0], P21[0], P22[0]};
                 } else {
-                    const R rinv = r_rcp<PPL, false>(r_mul(d1, d2));
-                    q1 = r_mul(d2, rinv);
-                    q2 = r_mul(d1, rinv);
+                    cc[0].u1 = if_get(W - 1, bsel, 0);
+                    cc[0].u2 = if_get(W - 1, bsel, 1);
+                    cc[0].p11 = if_get(W - 1, bsel, 2);
+                    cc[0].p12 = if_get(W - 1, bsel, 3);
+                    cc[0].p21 = if_get(W - 1, bsel, 4);
+                    cc[0].p22 = if_get(W - 1, bsel, 5);
                 }
-                const R o11 = r_mul(r_fma_s(taut, u1x, P11[t]), q1);
-                const R o12 = r_mul(r_fma_s(taut, u1y, P12[t]), q1);
-                const R o21 = r_mul(r_fma_s(taut, u2x, P21[t]), q2);
-                const R o22 = r_mul(r_fma_s(taut, u2y, P22[t]), q2);
-                const R ou1 = U1[t], ou2 = U2[t];
-                P11[t] = c_p11;
-                P12[t] = c_p12;
-                P21[t] = c_p21;
-                P22[t] = c_p22;
-                U1[t] = n1;
-                U2[t] = n2;
-                c_u1 = ou1;
-                c_u2 = ou2;
-                c_p11 = o11;
-                c_p12 = o12;
-                c_p21 = o21;
-                c_p22 = o22;
-            };
-            // ring slot of the constants of level t's incoming row, s - LAG - t
+            }
+#pragma clang loop unroll(full)
+            for (int c = 1; c < NCH; ++c) cc[c] = latch[c - 1];
+            // ring slot of the constants of level t's incoming row, s - LAG - lpos(t)
             auto slot_of = [&](int t) {
-                const int c = (LAG + t) % NRING;
+                const int c = (LAG + SH::lpos(t)) % NRING;
                 return s0 - c < 0 ? s0 - c + NRING : s0 - c;
             };
-            const int rs = ys + s - LAG;  // the row coming into this wave's first level
-            bool emitted;
             if constexpr (STEADY) {
-                // every level of the wave works and no row is the image's last: straight-line code; the constants of
-                // level t + 1 are fetched from the ring while level t computes
-                R q[kNF_RO] = {r0[0], r0[1], r0[2], r0[3]};
-                if constexpr (!FIRST) {
-                    const int slot = slot_of(0);
+                // every level of the wave works and no row is the image's last: straight-line code.  The levels are
+                // issued round by round -- round i = level i of every chain, independent of each other -- and the
+                // constants of round i + 1 are fetched from the ring while round i computes
+                R q[NCH][kNF_RO];
 #pragma clang loop unroll(full)
-                    for (int f = 0; f < kNF_RO; ++f) q[f] = ring_get(slot, f);
-                }
+                for (int c = 0; c < NCH; ++c) {
+                    if (FIRST && c == 0) {
 #pragma clang loop unroll(full)
-                for (int t = 0; t < KH; ++t) {
-                    R nq[kNF_RO] = {zero, zero, zero, zero};
-                    if (t + 1 < KH) {
-                        const int slot = slot_of(t + 1);
+                        for (int f = 0; f < kNF_RO; ++f) q[c][f] = r0[f];
+                    } else if (VA_TIMING_SKIP & 8) {
 #pragma clang loop unroll(full)
-                        for (int f = 0; f < kNF_RO; ++f) nq[f] = ring_get(slot, f);
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int f = 0; f < kNF_RO; ++f) q[c][f] = rprev[f];
+                    } else {
+                        const int slot = slot_of(c * KC);
+#pragma clang loop unroll(full)
+                        for (int f = 0; f < kNF_RO; ++f) q[c][f] = ring_get(slot, f);
                     }
-                    level(t, q[0], q[1], q[2], q[3], 1.0f, std::true_type{});
-#pragma clang loop unroll(full)
-                    for (int f = 0; f < kNF_RO; ++f) q[f] = nq[f];
                 }
-                emitted = true;
+#pragma clang loop unroll(full)
+                for (int i = 0; i < KC; ++i) {
+                    R nq[NCH][kNF_RO];
+#pragma clang loop unroll(full)
+                    for (int c = 0; c < NCH; ++c)
+#pragma clang loop unroll(full)
+                        for (int f = 0; f < kNF_RO; ++f) nq[c][f] = zero;
+                    if (i + 1 < KC) {
+#pragma clang loop unroll(full)
+                        for (int c = 0; c < NCH; ++c) {
+                            const int slot = slot_of(c * KC + i + 1);
+#pragma clang loop unroll(full)
+                            for (int f = 0; f < kNF_RO; ++f) nq[c][f] = (VA_TIMING_SKIP & 8) ? q[c][f] : ring_get(slot, f);
+                        }
+                        if (!(VA_TIMING_SKIP & 16)) __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma clang loop unroll(full)
+                    for (int c = 0; c < NCH; ++c) level(c * KC + i, cc[c], q[c][0], q[c][1], q[c][2], q[c][3], 1.0f, std::true_type{});
+#pragma clang loop unroll(full)
+                    for (int c = 0; c < NCH; ++c)
+#pragma clang loop unroll(full)
+                        for (int f = 0; f < kNF_RO; ++f) q[c][f] = nq[c][f];
+                }
             } else {
-                emitted = false;
 #pragma clang loop unroll(full)
                 for (int t = 0; t < KH; ++t) {
                     // global level g takes the rows [a0 - (K - g), b0 + (K - g)) of the image and, at the image bottom,
                     // the dummy row h
-                    const int g = G0 + t, rin = rs - t;
+                    const int g = G0 + t, rin = ys + s - LAG - SH::lpos(t);
                     const int lo = d_max(0, a0 - (K - g)), hi = d_min(h, b0 + (K - g) - 1);
                     const bool act = g < K && rin >= lo && rin <= hi;
-                    if (g == K - 1) emitted = act;
                     if (act) {
                         const float my = rin - 1 < h - 1 ? 1.0f : 0.0f;
                         if (FIRST && t == 0) {
-                            level(0, r0[0], r0[1], r0[2], r0[3], my, std::false_type{});
+                            level(0, cc[0], r0[0], r0[1], r0[2], r0[3], my, std::false_type{});
                         } else {
                             const int slot = slot_of(t);
-                            level(t, ring_get(slot, 0), ring_get(slot, 1), ring_get(slot, 2), ring_get(slot, 3), my, std::false_type{});
+                            level(t, cc[t / KC], ring_get(slot, 0), ring_get(slot, 1), ring_get(slot, 2), ring_get(slot, 3), my, std::false_type{});
                         }
                     }
                 }
             }
+#pragma clang loop unroll(full)
+            for (int c = 0; c + 1 < NCH; ++c) latch[c] = cc[c];
+            const SR& co = cc[NCH - 1];
             if constexpr (LAST) {
-                const int rout = ys + s - W - K;  // the row that left level K-1 in this step, K iterations on
-                if (emitted && stok && rout >= a0 && rout < b0) {
-                    st(c_u1, 0, rout);
-                    st(c_u2, 1, rout);
-                    st(c_p11, 2, rout);
-                    st(c_p12, 3, rout);
-                    st(c_p21, 4, rout);
-                    st(c_p22, 5, rout);
+                // the row that leaves the pipeline in this step: K iterations on, one step later per chain end on its way
+                const int rout = ys + s - K - (NWV * NCH - 1);
+                if (stok && rout >= a0 && rout < b0 && !(STEADY && (VA_TIMING_SKIP & 1))) {
+                    st(co.u1, 0, rout);
+                    st(co.u2, 1, rout);
+                    st(co.p11, 2, rout);
+                    st(co.p12, 3, rout);
+                    st(co.p21, 4, rout);
+                    st(co.p22, 5, rout);
                 }
             } else {
                 const int bsel = s & 1;
-                if_put(W, bsel, 0, c_u1);
-                if_put(W, bsel, 1, c_u2);
-                if_put(W, bsel, 2, c_p11);
-                if_put(W, bsel, 3, c_p12);
-                if_put(W, bsel, 4, c_p21);
-                if_put(W, bsel, 5, c_p22);
+                if (!(STEADY && (VA_TIMING_SKIP & 4))) {
+                    if_put(W, bsel, 0, co.u1);
+                    if_put(W, bsel, 1, co.u2);
+                    if_put(W, bsel, 2, co.p11);
+                    if_put(W, bsel, 3, co.p12);
+                    if_put(W, bsel, 4, co.p21);
+                    if_put(W, bsel, 5, co.p22);
+                }
             }
             if constexpr (FIRST) {
                 if constexpr (NWV == 1) {
@@ -1138,18 +1206,24 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
             // hand-over barrier: LDS traffic only (no wait for the global loads in flight or the stores just issued)
             if constexpr (NWV > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         };
-        // steady state of this wave: steps [s_a, s_b) (all its KH levels inside their row windows, below the last row)
-        int s_a = d_max(KH - 1, a0 - K + G0 + 2 * KH - 2) - ys + LAG;
-        int s_b = d_min(nsteps, d_min(h - 1, b0 + K - G0 - 1) - ys + LAG + 1);
+        // steady state of this wave: the steps in which all its KH levels are inside their row windows and below the
+        // image's last row -- level t (global g) takes row ys + s - LAG - lpos(t), its window is [lo_g, min(hi_g, h - 1)]
+        int s_a = 0, s_b = nsteps;
+#pragma clang loop unroll(full)
+        for (int t = 0; t < KH; ++t) {
+            const int g = G0 + t, p = LAG + SH::lpos(t) - ys;
+            s_a = d_max(s_a, d_max(0, a0 - (K - g)) + p);
+            s_b = d_min(s_b, d_min(h - 1, d_min(h, b0 + (K - g) - 1)) + p + 1);
+        }
         if (K < G0 + KH || s_a > s_b || !active) s_a = s_b = 0;
         int s = 0;
         for (; s < s_a; ++s) step(s, std::false_type{});
 #if VA_STREAM_UNROLL2
         // two steady steps per loop trip: the rows a level hands on and keeps (c_* -> P[t], n -> U[t]) change registers
         // by renaming between the two copies instead of by v_mov (5 per level and step otherwise).  Not in the one-wave
-        // form: with ten levels in one wave's 256 registers the second copy spills (19-21 registers; 1280x720: 62 instead
-        // of 114 pairs/s)
-        if constexpr (NWV > 1)
+        // form at two waves per SIMD: with ten levels in one wave's 256 registers the second copy spills (19-21 registers;
+        // 1280x720: 62 instead of 114 pairs/s)
+        if constexpr (NWV > 1 || KH > 10)
             for (; s + 1 < s_b; s += 2) {
                 step(s, std::true_type{});
                 step(s + 1, std::true_type{});
@@ -1169,7 +1243,7 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
 }
 
 // One launch = one pass (a.K iterations) of every pair of the call: the grid is (strips x chunks, pairs).
-template <int PPL, int KH, int NWV, bool FAST>
+template <int PPL, int KH, int NWV, bool FAST, int NCH = 1>
 __global__ void __launch_bounds__(NWV * 64)
     __attribute__((amdgpu_waves_per_eu((NWV == 1 && KH > 10) ? 1 : 2, (NWV == 1 && KH > 10) ? 1 : 2)))
     k_iter_stream(StreamArgs a)
@@ -1180,7 +1254,7 @@ __global__ void __launch_bounds__(NWV * 64)
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
         if (a.rev) lid = nb - 1 - lid;
     }
-    stream_job<PPL, KH, NWV, FAST>(a, a.pair0 + (int)(lid / gridDim.x), (int)(lid % gridDim.x), a.K, a.sin, a.sout);
+    stream_job<PPL, KH, NWV, FAST, 1, NCH>(a, a.pair0 + (int)(lid / gridDim.x), (int)(lid % gridDim.x), a.K, a.sin, a.sout);
 }
 
 #ifdef VA_EXPERIMENTS  // measured-slower kernel families: k_iter_stream4, k_iter_stream_q, k_iter_rows
@@ -1667,6 +1741,7 @@ constexpr int stream_kh2(int ppl) { return ppl == 2 ? kStreamKH2 : 5; }
 constexpr int kStreamBit = 1 << 8;  // va_tvl1_params.tile_mask bit: iterate with k_iter_stream
 struct StreamPick {
     int nsx, nch, R, HX, two, ppl, deep1;
+    int chains;  // chains of levels per wave (stream_job, NCH): 1, or 2 with stream_waves = 5 (one deep wave) / 6 (two waves)
 };
 // Pixels per lane of k_iter_stream: 2 (128-column strips) unless va_tvl1_params.stream_ppl asks for 3 (192-column
 // strips: a 129..192-column level then is ONE strip without x halo -- 179^2 fills 93 % of the lanes instead of 70 % of
@@ -1702,7 +1777,8 @@ void stream_strips(const va_tvl1_params* p, int w, StreamPick& sp)
     sp.two = p->tuning[VA_TUNE_STREAM_WAVES] != 1 && tiles_1d(w, SW, va_cdiv(2 * stream_kh2(sp.ppl), hq) * hq) <= 2;
     // stream_waves == 3 (experiment): where the two-wave pipeline would run, ONE wave with all 16 levels and the whole
     // register file of its SIMD (no hand-over, no barrier)
-    sp.deep1 = sp.two && p->tuning[VA_TUNE_STREAM_WAVES] == 3 && sp.ppl == 2;
+    sp.deep1 = sp.two && (p->tuning[VA_TUNE_STREAM_WAVES] == 3 || p->tuning[VA_TUNE_STREAM_WAVES] == 5) && sp.ppl == 2;
+    sp.chains = sp.two && sp.ppl == 2 && (p->tuning[VA_TUNE_STREAM_WAVES] == 5 || p->tuning[VA_TUNE_STREAM_WAVES] == 6) ? 2 : 1;
     // (Also measured, round 2, and removed again: THREE waves of 4 / 5 levels each -- 12 / 15 iterations per pass at 144 /
     // 168 registers, i.e. three resident waves per SIMD instead of two: 45.2 / 43.9 ms on the 224^2 level and 35.3 / 34.8
     // on 179^2 against 41.6 / 32.9 for the two-wave form: more resident waves do not fill the idle issue slots.)
@@ -1870,7 +1946,7 @@ struct Plan {
     int ns, ws[kMaxScales], hs[kMaxScales], pitch[kMaxScales];
     int lk[kMaxScales];        // LK_TILE / LK_STREAM / LK_ROWS per level
     RowsPick rows[kMaxScales];
-    size_t plane[kMaxScales];
+    size_t plane[kMaxScales], plane_max;
     int NF, NP, F;
     size_t off_pyr[kMaxScales], off_tmp, off_state[2], off_ro, off_err, off_sel, off_ctl, total;
     int ctl_words;  // k_iter_stream_q: head, abort flag and one completion counter per (pair, pass)
@@ -1907,10 +1983,11 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
                  "va_tvl1: rows_levels must be -1 or a level bit set, rows_cfg in [0,255]");
     VA_CHECK_ARG(p->tuning[VA_TUNE_STREAM_PPL] == 0 || p->tuning[VA_TUNE_STREAM_PPL] == 2 || p->tuning[VA_TUNE_STREAM_PPL] == 3, "va_tvl1: stream_ppl must be 0 (default), 2 or 3");
     VA_CHECK_ARG(p->tuning[VA_TUNE_STREAM_QUEUE] >= 0 && p->tuning[VA_TUNE_STREAM_QUEUE] <= 2, "va_tvl1: stream_queue must be 0 (default), 1 (queued) or 2 (a launch per pass)");
-    VA_CHECK_ARG(p->tuning[VA_TUNE_STREAM_LEVELS] >= -1 && p->tuning[VA_TUNE_STREAM_LEVELS] < (1 << kMaxScales) && (p->tuning[VA_TUNE_STREAM_WAVES] == 0 || p->tuning[VA_TUNE_STREAM_WAVES] == 1 || p->tuning[VA_TUNE_STREAM_WAVES] == 3 || p->tuning[VA_TUNE_STREAM_WAVES] == 4) &&
+    VA_CHECK_ARG(p->tuning[VA_TUNE_STREAM_LEVELS] >= -1 && p->tuning[VA_TUNE_STREAM_LEVELS] < (1 << kMaxScales) && (p->tuning[VA_TUNE_STREAM_WAVES] == 0 || p->tuning[VA_TUNE_STREAM_WAVES] == 1 || (p->tuning[VA_TUNE_STREAM_WAVES] >= 3 && p->tuning[VA_TUNE_STREAM_WAVES] <= 6)) &&
                      p->tuning[VA_TUNE_STREAM_CHUNKS] >= 0 && p->tuning[VA_TUNE_STREAM_SLOTS] >= 0,
-                 "va_tvl1: stream_levels must be -1 or a level bit set, stream_waves one of 0, 1, 3, 4, stream_chunks and stream_slots >= 0");
+                 "va_tvl1: stream_levels must be -1 or a level bit set, stream_waves one of 0, 1, 3, 4, 5, 6, stream_chunks and stream_slots >= 0");
     VA_CHECK_ARG(p->tau / p->theta <= 1000.0f && p->lambda * p->theta <= 1000.0f, "va_tvl1: tau/theta and lambda*theta must be <= 1000");
+    VA_CHECK_ARG(!(p->tuning[VA_TUNE_STREAM_WAVES] == 3 && p->fast_math), "va_tvl1: stream_waves = 3 (one deep wave) is compiled for the exact arithmetic only");
     if (!kVaExperiments) {
         const int sw = p->tuning[VA_TUNE_STREAM_WAVES];
         VA_CHECK_ARG(sw != 3 && sw != 4 && p->tuning[VA_TUNE_STREAM_PPL] != 3 && p->tuning[VA_TUNE_STREAM_QUEUE] != 1 &&
@@ -1950,11 +2027,16 @@ void make_plan(Plan& P, int w, int h, int n_seq, int fps, const va_tvl1_params* 
         P.off_pyr[s] = off;
         off += va_align_up((size_t)P.NF * 3 * P.plane[s] * sizeof(float), 256);
     }
+    // the buffers every level shares are sized for the LARGEST plane: a coarser level can have the larger one when the
+    // levels' pitches are padded differently (a 12-float pitch on a narrow, tall level: 16 x 100 -> pitch 16, plane 1600
+    // at level 0, but pitch 24, plane 1920 at level 1 when only that level is iterated by k_iter_rows)
+    P.plane_max = 0;
+    for (int s = 0; s < P.ns; ++s) P.plane_max = P.plane[s] > P.plane_max ? P.plane[s] : P.plane_max;
     P.off_tmp = off;
-    off += va_align_up((size_t)P.NF * 2 * P.plane[0] * sizeof(float), 256);
+    off += va_align_up((size_t)P.NF * 2 * P.plane_max * sizeof(float), 256);
     for (int b = 0; b < 2; ++b) {
         P.off_state[b] = off;
-        off += va_align_up((size_t)P.NP * kNF_STATE * P.plane[0] * sizeof(float), 256);
+        off += va_align_up((size_t)P.NP * kNF_STATE * P.plane_max * sizeof(float), 256);
     }
     // k_iter_rows reaches both state buffers through one 32-bit buffer resource; a batch too large for that streams instead
     // (same plain row order, any even pitch)
@@ -1962,7 +2044,7 @@ void make_plan(Plan& P, int w, int h, int n_seq, int fps, const va_tvl1_params* 
         if (P.lk[s] == LK_ROWS && (P.off_state[1] - P.off_state[0]) + (size_t)kNF_STATE * P.plane[s] * sizeof(float) >= 2147483648ull)
             P.lk[s] = LK_STREAM;
     P.off_ro = off;
-    off += va_align_up((size_t)P.NP * kNF_RO * P.plane[0] * sizeof(float), 256);
+    off += va_align_up((size_t)P.NP * kNF_RO * P.plane_max * sizeof(float), 256);
     P.off_err = off;
     if (p->epsilon > 0.0f) off += va_align_up((size_t)P.NP * p->iters * sizeof(unsigned long long), 256);
     P.off_sel = off;
@@ -2085,7 +2167,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
     float* pyr[kMaxScales];
     for (int s = 0; s < P.ns; ++s) pyr[s] = (float*)(ws + P.off_pyr[s]);
     float* tmp1 = (float*)(ws + P.off_tmp);
-    float* tmp2 = tmp1 + (size_t)P.NF * P.plane[0];
+    float* tmp2 = tmp1 + (size_t)P.NF * P.plane_max;
     float* state[2] = {(float*)(ws + P.off_state[0]), (float*)(ws + P.off_state[1])};
     float* ro = (float*)(ws + P.off_ro);
     unsigned long long* err = (unsigned long long*)(ws + P.off_err);
@@ -2108,10 +2190,10 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
     for (int s = 1; s < P.ns; ++s) {
         const int pw = P.ws[s - 1], ph = P.hs[s - 1], pp = P.pitch[s - 1];
         const dim3 g(va_cdiv(pw * ph, TPB), P.NF);
-        k_gauss<false><<<g, TPB, 0, st>>>(pyr[s - 1], 3 * P.plane[s - 1], tmp1, P.plane[0], pw, ph, pp, taps);
-        k_gauss<true><<<g, TPB, 0, st>>>(tmp1, P.plane[0], tmp2, P.plane[0], pw, ph, pp, taps);
+        k_gauss<false><<<g, TPB, 0, st>>>(pyr[s - 1], 3 * P.plane[s - 1], tmp1, P.plane_max, pw, ph, pp, taps);
+        k_gauss<true><<<g, TPB, 0, st>>>(tmp1, P.plane_max, tmp2, P.plane_max, pw, ph, pp, taps);
         const dim3 g2(va_cdiv(P.ws[s] * P.hs[s], TPB), P.NF);
-        k_resample<<<g2, TPB, 0, st>>>(tmp2, P.plane[0], pw, ph, pp, pyr[s], 3 * P.plane[s], P.ws[s], P.hs[s], P.pitch[s]);
+        k_resample<<<g2, TPB, 0, st>>>(tmp2, P.plane_max, pw, ph, pp, pyr[s], 3 * P.plane[s], P.ws[s], P.hs[s], P.pitch[s]);
         VA_LAUNCH_CHECK();
     }
     for (int s = 0; s < P.ns; ++s) {
@@ -2263,6 +2345,7 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                     const int nwg = qa.npairs * qa.tpp < want ? qa.npairs * qa.tpp : want;
                     if (p->fast_math) k_iter_stream_q<2, kStreamKH2, 2, true><<<nwg, 128, 0, st>>>(qa);
                     else k_iter_stream_q<2, kStreamKH2, 2, false><<<nwg, 128, 0, st>>>(qa);
+                    VA_LAUNCH_CHECK();
                     cur ^= qn & 1;
                     launches = 1;
                 }
@@ -2276,6 +2359,13 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                     sa.sin = state[cur];
                     sa.sout = state[cur ^ 1];
                     sa.rev = VA_REV ? (launches & 1) : 0;
+                    if (sp.deep1 && sp.chains == 2) {
+                        if (p->fast_math) k_iter_stream<2, 16, 1, true, 2><<<grid, 64, 0, st>>>(sa);
+                        else k_iter_stream<2, 16, 1, false, 2><<<grid, 64, 0, st>>>(sa);
+                    } else if (w2 && sp.chains == 2) {
+                        if (p->fast_math) k_iter_stream<2, kStreamKH2, 2, true, 2><<<grid, 128, 0, st>>>(sa);
+                        else k_iter_stream<2, kStreamKH2, 2, false, 2><<<grid, 128, 0, st>>>(sa);
+                    } else
 #ifdef VA_EXPERIMENTS
                     if (sp.deep1) {
                         k_iter_stream<2, 16, 1, false><<<grid, 64, 0, st>>>(sa);

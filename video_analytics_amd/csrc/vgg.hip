@@ -1622,6 +1622,14 @@ struct FcArgs {
 };
 
 // One workgroup: 32 rows (batch) x 128 columns x one K slice.  4 waves, each 32x32.
+// The weights are read once (FC1: 411 MB per model and batch) and every byte is used for only 32 rows: the kernel is a
+// stream of HBM reads, and what it needs is BYTES IN FLIGHT -- about 2 us of latency x 8 TB/s = 16 MB over the chip, 64 KB
+// per CU.  Round 2's loop kept ONE 16-float step per thread in registers beside the one in LDS (12 KB per workgroup,
+// two workgroups per CU: 2.3 TB/s, latency-bound).  Now a ring of kFcDepth register sets holds the steps t + 1 ..
+// t + kFcDepth while step t is multiplied out of LDS: 48 B x kFcDepth per thread = 48 KB per workgroup in flight; the loads
+// return in order, so the set that goes to LDS next is always the oldest one outstanding (counted vmcnt, no full drain).
+// Same products, same order of accumulation per slab as before (K ascending inside a slice, slabs reduced in fixed order).
+constexpr int kFcDepth = 4;
 __global__ void __launch_bounds__(256) k_fc_splitk(FcArgs a)
 {
     __shared__ __attribute__((aligned(16))) float sA[2][32 * kLdsStride];
@@ -1635,42 +1643,47 @@ __global__ void __launch_bounds__(256) k_fc_splitk(FcArgs a)
     const int T = (kend - k0) / kBK;
     const int q = tid & 3, rowbase = tid >> 2;
 
+    // Every load is UNCONDITIONAL (rows beyond M / columns beyond N read row 0 instead: their products land in slab rows /
+    // columns k_fc_reduce never reads; steps beyond the slice re-read its last step): a branch around a load makes the
+    // compiler's wait-count pass fall back to vmcnt(0) at every use, which would drain the whole ring at every step.
     const bool a_loader = rowbase < 32;
-    const bool a_ok = a_loader && (m0 + rowbase) < a.M;
-    const float* arow = a.A + (size_t)(m0 + (a_ok ? rowbase : 0)) * a.K + 4 * q;
+    const int am = m0 + (rowbase & 31);
+    const float* arow = a.A + (size_t)(am < a.M ? am : 0) * a.K + 4 * q;
     const float* brow[2];
-    bool b_ok[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int n = n0 + rowbase + 64 * i;
-        b_ok[i] = n < a.N;
-        brow[i] = a.Wt + (size_t)(b_ok[i] ? n : 0) * a.K + 4 * q;
+        brow[i] = a.Wt + (size_t)(n < a.N ? n : 0) * a.K + 4 * q;
     }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    float4 ra, rb[2];
-    auto gload = [&](int t) {
-        const int k = k0 + t * kBK;
-        ra = a_ok ? *reinterpret_cast<const float4*>(arow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 ra[kFcDepth], rb[kFcDepth][2];
+    const int tlast = T > 0 ? T - 1 : 0;
+    auto gload = [&](auto jc, int t) {  // step min(t, T - 1) of the slice into register set j
+        constexpr int j = decltype(jc)::value;
+        const int k = k0 + (t < tlast ? t : tlast) * kBK;
+        ra[j] = *reinterpret_cast<const f32x4*>(arow + k);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(brow[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < 2; ++i) rb[j][i] = *reinterpret_cast<const f32x4*>(brow[i] + k);
     };
-    auto lstore = [&](int buf) {
-        if (a_loader) *reinterpret_cast<float4*>(&sA[buf][rowbase * kLdsStride + 4 * q]) = ra;
+    auto lstore = [&](auto jc, int buf) {
+        constexpr int j = decltype(jc)::value;
+        if (a_loader) *reinterpret_cast<f32x4*>(&sA[buf][rowbase * kLdsStride + 4 * q]) = ra[j];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&sB[buf][(rowbase + 64 * i) * kLdsStride + 4 * q]) = rb[i];
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&sB[buf][(rowbase + 64 * i) * kLdsStride + 4 * q]) = rb[j][i];
     };
     const int r31 = lane & 31, hh = lane >> 5;
-    if (T > 0) {
-        gload(0);
-        lstore(0);
-    }
+    if (T <= 0) return;  // (uniform; a slice always has at least one step)
+    // prologue: steps 0 .. kFcDepth - 1 on their way, step 0 into LDS, then its set refilled with step kFcDepth
+    static_for<kFcDepth>([&](auto jc) { gload(jc, jc.value); });
+    lstore(std::integral_constant<int, 0>{}, 0);
+    gload(std::integral_constant<int, 0>{}, kFcDepth);
     __syncthreads();
-    for (int t = 0; t < T; ++t) {
+    // step t sits in LDS buffer t & 1; register set (t + 1) % kFcDepth holds step t + 1 (the oldest load outstanding)
+    auto body = [&](auto jc, int t) {
+        constexpr int jn = (decltype(jc)::value + 1) % kFcDepth;  // set of step t + 1, where t % kFcDepth == jc
         const int buf = t & 1;
-        if (t + 1 < T) gload(t + 1);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const float4 fa = *reinterpret_cast<const float4*>(&sA[buf][r31 * kLdsStride + 8 * g + 4 * hh]);
@@ -1680,9 +1693,16 @@ __global__ void __launch_bounds__(256) k_fc_splitk(FcArgs a)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
         }
-        if (t + 1 < T) lstore(buf ^ 1);
+        lstore(std::integral_constant<int, jn>{}, buf ^ 1);  // (past the last step: a copy of it that nobody multiplies)
+        gload(std::integral_constant<int, jn>{}, t + 1 + kFcDepth);
         __syncthreads();
-    }
+    };
+    int t = 0;
+    for (; t + kFcDepth <= T; t += kFcDepth)
+        static_for<kFcDepth>([&](auto jc) { body(jc, t + jc.value); });
+    static_for<kFcDepth>([&](auto jc) {
+        if (t + jc.value < T) body(jc, t + jc.value);
+    });
     // slab[s][m][n]
     const int n = n0 + wave * 32 + r31;
     const size_t Mp = (size_t)gridDim.y * 32;

@@ -74,9 +74,15 @@ class TwoStreamPipeline(object):
         return vflow.flow_to_stack(fl).view(B, 2 * self.L, H, W)
 
     def _buffer(self, bank, k, shape):
+        """Slot k's buffer, re-allocated when the batch shape changes (a ragged last batch).  The buffers are allocated on
+        the caller's stream but read and written on the pipeline's own streams: every one of those is recorded on the
+        tensor, so that the caching allocator cannot hand a dropped buffer's block to a new caller-stream allocation while
+        a quantisation on the CNN stream (or a TV-L1 call) that still uses it is pending."""
         t = bank[k]
         if t is None or tuple(t.shape) != tuple(shape):
             bank[k] = t = torch.empty(shape, dtype=torch.float32, device=self.device)
+            for st in [self._cnn, self._cnn2] + list(vflow.flow_streams(self.device, self.flow_streams)):
+                t.record_stream(st)
         return t
 
     def submit(self, rgb, gray=None, flow_stack=None):

@@ -269,7 +269,7 @@ class Vgg16Stream(object):
         _ffi.check(_ffi.lib().va_vgg16_import_state(self._h, int(bool(momentum)), arr(*[p(t) for t in state["conv_w"]]),
                                                     arr(*[p(t) for t in state["conv_b"]]), arr4(*[p(t) for t in state["fc_w"]]),
                                                     arr4(*[p(t) for t in state["fc_b"]]), _ffi.stream_ptr(self.device)))
-        torch.cuda.current_stream().synchronize()  # `keep` must outlive the copies
+        torch.cuda.current_stream(self.device).synchronize()  # `keep` must outlive the copies (the model's device, not the thread's current one)
         del keep
 
 
