@@ -262,7 +262,12 @@ def test_bf16_stream_against_its_own_restatement_and_across_staging_schemes(weig
     feat_r, desc_r, log_r = vgg_oracle.forward_bf16(x, w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"])
     outs = []
     from video_analytics_amd import _ffi
-    for variant in (0, 1, 2, 5, 7):  # (5: the two-group kernel, 7: the weights-resident kernel -- the same K order per accumulator, so bit-equal too)
+    # Two groups of schemes, each adding the same products in the same order per accumulator, so bit-equal inside a group:
+    # (0, 5, 7) -- the automatic choice, the two-group kernel, the weights-resident kernel -- run the 14 x 14 layers on the
+    # one-image-per-workgroup kernel (round 3: chunk-major K order there); (1, 2) keep the tap-major kernel on every layer.
+    # Between the groups: the bf16 noise level, like any two valid bf16 evaluations.
+    variants = (0, 5, 7, 1, 2)
+    for variant in variants:
         m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256, dtype="bf16")
         m.set_option(_ffi.VA_OPT_BF16_VARIANT, variant)
         feat, desc, logits = m.forward(x.cuda(), want_feat=True)
@@ -270,11 +275,14 @@ def test_bf16_stream_against_its_own_restatement_and_across_staging_schemes(weig
         assert torch.equal(feat, feat2) and torch.equal(logits, logits2)
         outs.append((feat.cpu(), logits.cpu()))
         m.close()
-    for f, l in outs[1:]:
-        assert torch.equal(f, outs[0][0]) and torch.equal(l, outs[0][1])
+    for k in (1, 2):
+        assert torch.equal(outs[k][0], outs[0][0]) and torch.equal(outs[k][1], outs[0][1]), variants[k]
+    assert torch.equal(outs[4][0], outs[3][0]) and torch.equal(outs[4][1], outs[3][1])
     fs, ls = float(feat_r.abs().max()), float(log_r.abs().max())
-    ef, el = float((outs[0][0] - feat_r).abs().max()), float((outs[0][1] - log_r).abs().max())
-    assert ef / fs < 1e-2 and el / ls < 1e-2, (ef, fs, el, ls)
+    for k in (0, 3):
+        ef, el = float((outs[k][0] - feat_r).abs().max()), float((outs[k][1] - log_r).abs().max())
+        assert ef / fs < 1e-2 and el / ls < 1e-2, (variants[k], ef, fs, el, ls)
+    assert float((outs[3][1] - outs[0][1]).abs().max()) / ls < 1e-2
     # variant 6: the two-group kernel on halo bricks (chunk-major K order in 32-channel chunks: another fp32 summation
     # order, so within the same bf16 noise of the restatement rather than bit-equal to the schemes above); deterministic
     m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256, dtype="bf16")

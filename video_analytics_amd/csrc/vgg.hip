@@ -1425,6 +1425,242 @@ __global__ void __launch_bounds__(256) k_conv3x3_ws_bf16(ConvArgsWs a)
     conv3x3_ws_body<POOL>(a);
 }
 
+// ---------------------------------------------------------------- bf16 conv3x3 on 14 x 14 images: one image per workgroup ----
+//
+// conv5_1 .. conv5_3 (512 -> 512 channels at 14 x 14): M = 196 pixels per image, K = 9 x 512.  The tap-major kernel above
+// runs them as 392 workgroups of 128 pixels x 64 channels that stage, per 64-channel K step, a fresh copy of the activations
+// for every one of the nine taps and every one of the eight channel tiles: 462 MB of activation staging + 231 MB of weights
+// per layer at batch 32, which at the measured 27-29 B/clk a CU takes in is its 51-54 us (23 % of the matrix pipe).
+// k_conv3x3_img14_bf16 gives every workgroup ONE WHOLE IMAGE and 64 output channels (batch 32: 32 x 8 = 256 workgroups, one
+// per CU, one round):
+//   * the image's 64-channel chunk is staged ONCE as a zero-bordered 16 x 16 halo brick (32 KB, double-buffered); the nine
+//     taps are formed by shifting the brick pixel a fragment row reads -- 1/9 of the activation staging, and 1/8 of it
+//     again because the brick serves all nine taps of the 64 output channels: 0.26 MB of activations + 0.59 MB of weights
+//     per workgroup instead of 2.7 MB;
+//   * weights stream through a ring of three 24 KB tiles (64 channels x one kernel ROW of three taps x 64 input channels),
+//     two steps ahead, counted s_waitcnt vmcnt; one barrier per step of 48 MFMAs per wave (24 steps per layer);
+//   * eight waves: four COMPUTING waves (one per SIMD: fragment reads one sub-step ahead + MFMAs, nothing else) and four
+//     LOADER waves (one per SIMD) that issue all LDS-DMA pieces, wait for them and certify them at the step's barrier;
+//   * the rows of the GEMM are the image's pixels in quad-major order (row 4 q + 2 dy + dx = pixel (2 qy + dy, 2 qx + dx) of
+//     quad q = 7 qy + qx): 196 rows in seven 32-row blocks (the last one 4 rows), so that the four registers of a lane's
+//     accumulator quad are one 2 x 2 pooling window; waves 0..2 own two row blocks, wave 3 one; both 32-channel column blocks;
+//   * K order is chunk-major (64-channel chunk outside, tap inside): another fp32 summation order than the tap-major
+//     kernels, so its results agree with theirs at the bf16 noise level, not bit for bit (like the first-layer paths).
+// POOLF32 = false: bf16 NHWC output (conv5_1, conv5_2); true: bias + ReLU + 2 x 2 max-pool, fp32 NHWC [B][7][7][Cout] (conv5_3).
+template <bool POOLF32>
+__device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
+{
+    // one step = one kernel ROW (three taps) of one 64-channel chunk: 48 MFMAs per computing wave between two barriers
+    constexpr int BRICK = 256 * kBfBK, WT = 3 * 64 * kBfBK, NWR = 3;  // bf16 elements: halo brick chunk, weight tile (3 taps); ring depth
+    constexpr int WPIECES = 6, BPIECES = 8;                            // a loader wave's 1 KB DMA pieces per weight tile / per brick chunk
+    __shared__ __attribute__((aligned(1024))) __bf16 smem[2 * BRICK + NWR * WT];
+    __bf16* const sBrick = smem;
+    __bf16* const sW = smem + 2 * BRICK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3: computing waves, 4..7: loader waves (one of each per SIMD)
+    const int wave = wave8 & 3;
+    const int tiles_n = a.Cout / 64;
+    // Workgroup id -> (channel tile, image): consecutive ids go round-robin over the 8 XCDs, so with id % tiles_n as the
+    // channel tile (8 tiles at 512 channels) every XCD works on ONE 64-channel slice of the weights (0.59 MB: resident in
+    // its L2, read by the XCD's 32 workgroups) -- the weight tile a step waits for then comes from L2, while the image
+    // bricks, which are fetched a whole chunk ahead, may come from further away.
+    const int n_tile = blockIdx.x % tiles_n, b = blockIdx.x / tiles_n;
+    const int n0 = n_tile * 64, Cin = a.Cin;
+    const int r31 = lane & 31, hh = lane >> 5, lrow = lane >> 3, lslot = lane & 7;
+    const int nchunks = Cin / kBfBK, T = 3 * nchunks;
+    // Brick pixel bp = 16 by + bx holds image pixel (by - 1, bx - 1), zeros on the border; its 16-byte chunk c sits at slot
+    // c ^ swz(bp) of its 128-byte line (swizzle on the source side, as above).  A fragment read's 16-lane groups hold four
+    // 2 x 2 quads: the pixels of a quad's two rows are 16 brick pixels = 2 KB apart, i.e. on the same banks, so the swizzle
+    // takes the row's parity as well: swz = ((bx >> 1) & 3) | ((by & 1) << 2).
+    auto brick_swz = [](int bp) { return ((bp >> 1) & 3) | (((bp >> 4) & 1) << 2); };
+
+    if (wave8 >= 4) {
+        // ------------------------------------------------------------------ loader waves ----
+        // An LDS-DMA piece costs the issuing wave 100-185 cycles of its instruction stream: issued by the computing waves
+        // (6-14 pieces per step in front of 48 MFMAs) they cost as much as the MFMAs themselves (46 us per layer, MFMA
+        // pipe 33 % busy).  Here they belong to a wave of their own on every SIMD, which does nothing else: it refills the
+        // ring behind the barrier, waits for its pieces of the NEXT step to land, and meets the computing waves at the
+        // next barrier -- its arrival is what tells them the tile is complete.
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<__bf16*>(a.in) + (size_t)b * 196 * Cin, 0, 196 * Cin * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<__bf16*>(a.wp) + (size_t)n0 * 9 * Cin, 0, 64 * 9 * Cin * 2, 0x00020000);
+        int aoff[BPIECES];  // brick pixels (8 wave + i) * 8 + lrow
+#pragma unroll
+        for (int i = 0; i < BPIECES; ++i) {
+            const int bp = ((wave * 8 + i) << 3) + lrow, by = bp >> 4, bx = bp & 15;
+            const bool ok = by >= 1 && by <= 14 && bx >= 1 && bx <= 14;
+            aoff[i] = ok ? (((by - 1) * 14 + (bx - 1)) * Cin + 8 * (lslot ^ brick_swz(bp))) * 2 : 0x7fffffff;  // out of range: zeros
+        }
+        int boff[2];  // output channels (2 wave + i) * 8 + lrow of a tap's 64 x 64 sub-tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 8 + lrow;
+            boff[i] = (row * 9 * Cin + 8 * (lslot ^ ((row >> 1) & 7))) * 2;
+        }
+        auto stage_brick = [&](int chunk) {
+            __bf16* const dst = sBrick + (chunk & 1) * BRICK;
+            static_for<BPIECES>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(dst + (wave * 8 + i) * 8 * kBfBK), 16, aoff[i], chunk * kBfBK * 2, 0, 0);
+            });
+        };
+        auto stage_w = [&](int t) {  // step t = 3 chunk + ky: weights [n][3 ky + kx][chunk * 64 ..], kx = 0, 1, 2
+            const int chunk = t / 3, ky = t - 3 * chunk;
+            __bf16* const dst = sW + (t % NWR) * WT;
+            static_for<WPIECES>([&](auto I) {
+                constexpr int i = decltype(I)::value, kx = i >> 1, h = i & 1;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(dst + kx * 64 * kBfBK + (wave * 2 + h) * 8 * kBfBK), 16, boff[h],
+                                                         ((3 * ky + kx) * Cin + chunk * kBfBK) * 2, 0, 0);
+            });
+        };
+        // prologue: brick 0, weight tiles of steps 0 and 1
+        stage_brick(0);
+        stage_w(0);
+        if (T > 1) stage_w(1);
+        bool brick_prev = false;  // a brick was issued in the previous step (it sits in the queue BEFORE that step's weight tile)
+        for (int t = 0; t < T; ++t) {
+            const int chunk = t / 3, ky = t - 3 * chunk;
+            // this wave's pieces of step t must have landed; younger ones may fly: the weight tile of step t + 1 (6 pieces) and,
+            // when a brick was issued in the step before (after tile t, before tile t + 1), its 8 pieces
+            // (queue at this point, oldest first: tile t | [brick, 8 pieces] | tile t + 1, 6 pieces)
+            if (t + 1 >= T) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (brick_prev) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // step t is complete in LDS; the computing waves have read step t - 1
+            // refills: the NEXT chunk's brick at the first row of this one (its buffer was last read in step t - 1), then the
+            // weight tile of step t + 2 (its slot held step t - 1)
+            brick_prev = ky == 0 && chunk + 1 < nchunks;
+            if (brick_prev) stage_brick(chunk + 1);
+            if (t + 2 < T) stage_w(t + 2);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- computing waves ----
+    // fragment rows: row blocks wave and wave + 4 (wave 3's second block is the dummy block 7: all rows read the brick's
+    // zero corner; its MFMAs cost nothing the other waves do not spend anyway)
+    constexpr int MT = 2, NT = 2;
+    const int nrb = wave < 3 ? 2 : 1;
+    int bp0[MT];  // centre-tap brick pixel of this lane's row in each block (0 = rows beyond the image: the zero corner pixel)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int r = 32 * (wave + 4 * i) + r31, quad = r >> 2, qy = quad / 7, qx = quad - 7 * qy;
+        const int y = 2 * qy + ((r >> 1) & 1), x = 2 * qx + (r & 1);
+        bp0[i] = (quad < 49 && wave + 4 * i < 7) ? (y + 1) * 16 + (x + 1) : 0;
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int fsw = (r31 >> 1) & 7;
+
+    for (int t = 0; t < T; ++t) {
+        const int chunk = t / 3, ky = t - 3 * chunk;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // the loader waves have seen step t land; every computing wave has read step t - 1
+        const __bf16* const sA = sBrick + (chunk & 1) * BRICK;
+        const __bf16* const sB = sW + (t % NWR) * WT;
+        // Six sub-steps (3 taps x 2 halves of the 64 channels) of 8 MFMAs, branch-free and fully unrolled; the 8 fragment reads
+        // of sub-step s + 1 are ISSUED BEFORE the MFMAs of sub-step s (sched_barrier pins that order) and waited for only at
+        // the start of s + 1: with one computing wave per SIMD nothing else covers the LDS latency.
+        int arow[3][MT], asw[3][MT];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int bp = bp0[i] ? bp0[i] + (ky - 1) * 16 + (kx - 1) : 0;
+                arow[kx][i] = bp * kBfBK;
+                asw[kx][i] = brick_swz(bp);
+            }
+        bf16x8 fa[2][2][MT], fb[2][2][NT];  // [buffer][half of the sub-step][block]
+        auto fetch = [&](auto SS, auto BUF) {
+            constexpr int ss = decltype(SS)::value, kx = ss >> 1, bf = decltype(BUF)::value;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ks = 2 * (ss & 1) + h;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[bf][h][i] = *reinterpret_cast<const bf16x8*>(&sA[arow[kx][i] + (((2 * ks + hh) ^ asw[kx][i]) << 3)]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    fb[bf][h][j] = *reinterpret_cast<const bf16x8*>(&sB[kx * 64 * kBfBK + (j * 32 + r31) * kBfBK + (((2 * ks + hh) ^ fsw) << 3)]);
+            }
+        };
+        fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        static_for<6>([&](auto SS) {
+            constexpr int ss = decltype(SS)::value, cur = ss & 1;
+            if constexpr (ss + 1 < 6) fetch(std::integral_constant<int, ss + 1>{}, std::integral_constant<int, cur ^ 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = POOLF32 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][h][i], fb[cur][h][j], acc[i][j], 0, 0, 0)
+                                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][h][j], fa[cur][h][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+
+    // ---- epilogue, straight from the accumulators (25 KB of output per workgroup against 0.85 MB staged)
+    if constexpr (POOLF32) {
+        // pixel fragment first: register 4 g4 + j of lane (r31, hh) is row 8 g4 + 4 hh + j of the block, channel r31 of the
+        // column block: the four registers are one quad = one pooling window
+        float* const out = (float*)a.out + (size_t)b * 49 * a.Cout;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if (i >= nrb) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + 32 * j + r31;
+                const float bias = a.bias[n];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int quad = 8 * (wave + 4 * i) + 2 * g4 + hh;
+                    if (quad >= 49) continue;
+                    const float m01 = fmaxf(acc[i][j][4 * g4 + 0], acc[i][j][4 * g4 + 1]), m23 = fmaxf(acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]);
+                    out[(size_t)quad * a.Cout + n] = fmaxf(fmaxf(m01, m23) + bias, 0.0f);  // max(relu(v + b)) = relu(max(v) + b)
+                }
+            }
+        }
+    } else {
+        // weight fragment first: register 4 g4 + j of lane (r31, hh) is channel 8 g4 + 4 hh + j of the column block, row r31
+        // of the row block: four consecutive channels of one pixel = one 8-byte store
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        __bf16* const out = (__bf16*)a.out + (size_t)b * 196 * a.Cout;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if (i >= nrb) continue;
+            const int r = 32 * (wave + 4 * i) + r31, quad = r >> 2, qy = quad / 7, qx = quad - 7 * qy;
+            if (quad >= 49) continue;
+            const int y = 2 * qy + ((r >> 1) & 1), x = 2 * qx + (r & 1);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int n = n0 + 32 * j + 8 * g4 + 4 * hh;
+                    const float4 bs = *(const float4*)(a.bias + n);
+                    bf16x4 v;
+                    v.x = (__bf16)fmaxf(acc[i][j][4 * g4 + 0] + bs.x, 0.0f);
+                    v.y = (__bf16)fmaxf(acc[i][j][4 * g4 + 1] + bs.y, 0.0f);
+                    v.z = (__bf16)fmaxf(acc[i][j][4 * g4 + 2] + bs.z, 0.0f);
+                    v.w = (__bf16)fmaxf(acc[i][j][4 * g4 + 3] + bs.w, 0.0f);
+                    *(bf16x4*)(out + (size_t)(y * 14 + x) * a.Cout + n) = v;
+                }
+        }
+    }
+}
+
+template <bool POOLF32>
+__global__ void __launch_bounds__(512) k_conv3x3_img14_bf16(ConvArgsBf a)
+{
+    conv3x3_img14_body<POOLF32>(a);
+}
+
 // ---------------------------------------------------------------- fp32 conv3x3, LDS-DMA staging ---------
 //
 // The bf16 kernel's structure (LDS-DMA with source-side swizzle, one 32 KB buffer, four workgroups per CU, or
@@ -1777,6 +2013,9 @@ constexpr long VA_RING_MAXGRID_F32 = 1024;  // fp32: the same threshold (0 and 4
 #ifndef VA_WS_DEFAULT
 #define VA_WS_DEFAULT 1     // bf16: the weights-resident kernel on the layers with 64 input channels
 #endif
+#ifndef VA_IMG14_DEFAULT
+#define VA_IMG14_DEFAULT 1  // bf16: the one-image-per-workgroup kernel on the 14 x 14 layers (k_conv3x3_img14_bf16)
+#endif
 #ifndef VA_BPP_DEFAULT
 #define VA_BPP_DEFAULT 0    // bf16: 1 = the two-group halo-brick kernel wherever it applies (set after measurement)
 #endif
@@ -1921,6 +2160,16 @@ int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const
             if (L.pool) k_conv3x3_pp_bf16<2, true><<<gridp, 512, 0, st>>>(a);
             else k_conv3x3_pp_bf16<2, false><<<gridp, 512, 0, st>>>(a);
         }
+        VA_LAUNCH_CHECK();
+        return VA_OK;
+    }
+    // 14 x 14 layers (conv5_x): one image x 64 output channels per workgroup, the image's halo brick staged once per
+    // 64-channel chunk (k_conv3x3_img14_bf16): the default there; variants 1, 2 keep the tap-major kernels for A/B and tests
+    if ((variant == 0 || variant >= 5) && VA_IMG14_DEFAULT && !L.xcol && L.hw == 14 && a.Cin % 64 == 0 && L.cout % 64 == 0 &&
+        (long)B * (L.cout / 64) <= 65535L * 16 && ((out_f32 && L.pool) || (!out_f32 && !L.pool))) {
+        const unsigned gridi = (unsigned)(B * (L.cout / 64));
+        if (out_f32) k_conv3x3_img14_bf16<true><<<gridi, 512, 0, st>>>(a);
+        else k_conv3x3_img14_bf16<false><<<gridi, 512, 0, st>>>(a);
         VA_LAUNCH_CHECK();
         return VA_OK;
     }
