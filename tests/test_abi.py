@@ -81,7 +81,7 @@ def test_tile_plan_of_the_benchmark_pyramid():
         ppl3 = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 8, stream_ppl=3))
         assert [(d["tile_w"], d["block_iters"], d["tiles_x"]) for d in ppl3] == [(192, 10, 2), (192, 10, 1), (192, 10, 1), (192, 10, 1), (192, 10, 1)]
     else:  # a default build refuses the experiment switches loudly instead of silently running something else
-        for kw in (dict(tile_mask=1 << 9), dict(stream_ppl=3), dict(stream_waves=3), dict(stream_waves=4), dict(stream_queue=1),
+        for kw in (dict(tile_mask=1 << 9), dict(stream_ppl=3), dict(stream_waves=3), dict(stream_waves=4), dict(stream_waves=5), dict(stream_waves=6), dict(stream_queue=1),
                    dict(rows_levels=1), dict(rows_cfg=40)):
             assert _ffi.lib().va_tvl1_workspace_bytes(224, 224, 1, 2, _ffi.default_tvl1_params(epsilon=0.0, **kw)) == 0, kw
             assert b"VA_EXPERIMENTS" in _ffi.lib().va_last_error()

@@ -110,6 +110,7 @@ def test_streaming_kernel_pixels_per_lane_bit_exact(oracle_tvl1, ppl, H, W, nch)
 @pytest.mark.parametrize("H,W,nch", [(224, 224, 0), (224, 224, 3), (100, 64, 3), (129, 225, 2), (57, 131, 1), (179, 179, 2), (114, 114, 1),
                                      (48, 64, 0), (17, 19, 0), (33, 130, 1)])
 def test_streaming_kernel_two_chains_per_wave_bit_exact(oracle_tvl1, waves, H, W, nch):
+    _needs_experiments()
     # stream_waves = 5 / 6: the levels of a wave are cut into TWO chains that are issued interleaved (the second chain takes
     # its rows from a register latch one step later): one deep wave with 2 x 8 levels / two waves with 2 x 4 levels each.
     # Iteration counts that do and do not fill the pipeline (16), passes that end in the first / second chain of the last

@@ -1990,10 +1990,10 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
     VA_CHECK_ARG(!(p->tuning[VA_TUNE_STREAM_WAVES] == 3 && p->fast_math), "va_tvl1: stream_waves = 3 (one deep wave) is compiled for the exact arithmetic only");
     if (!kVaExperiments) {
         const int sw = p->tuning[VA_TUNE_STREAM_WAVES];
-        VA_CHECK_ARG(sw != 3 && sw != 4 && p->tuning[VA_TUNE_STREAM_PPL] != 3 && p->tuning[VA_TUNE_STREAM_QUEUE] != 1 &&
+        VA_CHECK_ARG(sw != 3 && sw != 4 && sw != 5 && sw != 6 && p->tuning[VA_TUNE_STREAM_PPL] != 3 && p->tuning[VA_TUNE_STREAM_QUEUE] != 1 &&
                          p->tuning[VA_TUNE_ROWS_LEVELS] <= 0 && p->tuning[VA_TUNE_ROWS_CFG] == 0 && !(p->tile_mask & kRowsBit),
                      "va_tvl1: this tuning value selects an experiment kernel (k_iter_rows, k_iter_stream_q, k_iter_stream4, one deep "
-                     "wave, 3 pixels per lane); build the library with -DVA_EXPERIMENTS (make EXPERIMENTS=1) to get them");
+                     "wave, two chains per wave, 3 pixels per lane); build the library with -DVA_EXPERIMENTS (make EXPERIMENTS=1) to get them");
     }
     return VA_OK;
 }
@@ -2359,15 +2359,14 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                     sa.sin = state[cur];
                     sa.sout = state[cur ^ 1];
                     sa.rev = VA_REV ? (launches & 1) : 0;
-                    if (sp.deep1 && sp.chains == 2) {
+#ifdef VA_EXPERIMENTS
+                    if (sp.deep1 && sp.chains == 2) {  // round 3: two interleaved chains of levels per wave (measured slower)
                         if (p->fast_math) k_iter_stream<2, 16, 1, true, 2><<<grid, 64, 0, st>>>(sa);
                         else k_iter_stream<2, 16, 1, false, 2><<<grid, 64, 0, st>>>(sa);
                     } else if (w2 && sp.chains == 2) {
                         if (p->fast_math) k_iter_stream<2, kStreamKH2, 2, true, 2><<<grid, 128, 0, st>>>(sa);
                         else k_iter_stream<2, kStreamKH2, 2, false, 2><<<grid, 128, 0, st>>>(sa);
-                    } else
-#ifdef VA_EXPERIMENTS
-                    if (sp.deep1) {
+                    } else if (sp.deep1) {
                         k_iter_stream<2, 16, 1, false><<<grid, 64, 0, st>>>(sa);
                     } else if (w2 && four) {
                         const int njobs = (int)(grid.x * grid.y), g4 = va_cdiv(njobs, 4);

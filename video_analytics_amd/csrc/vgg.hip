@@ -1441,12 +1441,19 @@ __global__ void __launch_bounds__(256) k_conv3x3_ws_bf16(ConvArgsWs a)
 //     two steps ahead, counted s_waitcnt vmcnt; one barrier per step of 48 MFMAs per wave (24 steps per layer);
 //   * eight waves: four COMPUTING waves (one per SIMD: fragment reads one sub-step ahead + MFMAs, nothing else) and four
 //     LOADER waves (one per SIMD) that issue all LDS-DMA pieces, wait for them and certify them at the step's barrier;
-//   * the rows of the GEMM are the image's pixels in quad-major order (row 4 q + 2 dy + dx = pixel (2 qy + dy, 2 qx + dx) of
-//     quad q = 7 qy + qx): 196 rows in seven 32-row blocks (the last one 4 rows), so that the four registers of a lane's
-//     accumulator quad are one 2 x 2 pooling window; waves 0..2 own two row blocks, wave 3 one; both 32-channel column blocks;
+//   * the rows of the GEMM are the image's pixels in quad order: row block qy (32 rows) = the seven 2 x 2 quads of quad row qy
+//     (row 4 qx + 2 dy + dx = pixel (2 qy + dy, 2 qx + dx)) + one dummy quad, so that the four registers of a lane's
+//     accumulator quad are one 2 x 2 pooling window AND the 16-lane groups of a fragment read (four quads: slots {0,3,5,6} or
+//     {1,2,4,7} of the block) hit 16 different bank positions under the brick's swizzle; waves 0..2 own two row blocks,
+//     wave 3 one (+ a dummy block of zero rows); both 32-channel column blocks;
 //   * K order is chunk-major (64-channel chunk outside, tap inside): another fp32 summation order than the tap-major
 //     kernels, so its results agree with theirs at the bf16 noise level, not bit for bit (like the first-layer paths).
 // POOLF32 = false: bf16 NHWC output (conv5_1, conv5_2); true: bias + ReLU + 2 x 2 max-pool, fp32 NHWC [B][7][7][Cout] (conv5_3).
+// TIMING BUILDS ONLY (wrong results): parts of k_conv3x3_img14_bf16's steps to leave out -- 1 = the MFMAs, 2 = the fragment
+// reads, 4 = the LDS-DMA refills inside the loop
+#ifndef VA_I14_SKIP
+#define VA_I14_SKIP 0
+#endif
 template <bool POOLF32>
 __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
 {
@@ -1530,9 +1537,9 @@ __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
             __builtin_amdgcn_s_barrier();  // step t is complete in LDS; the computing waves have read step t - 1
             // refills: the NEXT chunk's brick at the first row of this one (its buffer was last read in step t - 1), then the
             // weight tile of step t + 2 (its slot held step t - 1)
-            brick_prev = ky == 0 && chunk + 1 < nchunks;
+            brick_prev = ky == 0 && chunk + 1 < nchunks && !(VA_I14_SKIP & 4);
             if (brick_prev) stage_brick(chunk + 1);
-            if (t + 2 < T) stage_w(t + 2);
+            if (t + 2 < T && !(VA_I14_SKIP & 4)) stage_w(t + 2);
         }
         return;
     }
@@ -1545,9 +1552,9 @@ __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
     int bp0[MT];  // centre-tap brick pixel of this lane's row in each block (0 = rows beyond the image: the zero corner pixel)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int r = 32 * (wave + 4 * i) + r31, quad = r >> 2, qy = quad / 7, qx = quad - 7 * qy;
-        const int y = 2 * qy + ((r >> 1) & 1), x = 2 * qx + (r & 1);
-        bp0[i] = (quad < 49 && wave + 4 * i < 7) ? (y + 1) * 16 + (x + 1) : 0;
+        const int qy = wave + 4 * i, qx = r31 >> 2;  // row block = quad row of the image; 8 quad slots, the last one a dummy
+        const int y = 2 * qy + ((r31 >> 1) & 1), x = 2 * qx + (r31 & 1);
+        bp0[i] = (qx < 7 && qy < 7) ? (y + 1) * 16 + (x + 1) : 0;
     }
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -1592,8 +1599,9 @@ __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
         fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         static_for<6>([&](auto SS) {
             constexpr int ss = decltype(SS)::value, cur = ss & 1;
-            if constexpr (ss + 1 < 6) fetch(std::integral_constant<int, ss + 1>{}, std::integral_constant<int, cur ^ 1>{});
+            if constexpr (ss + 1 < 6 && !(VA_I14_SKIP & 2)) fetch(std::integral_constant<int, ss + 1>{}, std::integral_constant<int, cur ^ 1>{});
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VA_I14_SKIP & 1))
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1620,8 +1628,9 @@ __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
                 const float bias = a.bias[n];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int quad = 8 * (wave + 4 * i) + 2 * g4 + hh;
-                    if (quad >= 49) continue;
+                    const int qy = wave + 4 * i, qx = 2 * g4 + hh;
+                    if (qx >= 7 || qy >= 7) continue;
+                    const int quad = 7 * qy + qx;
                     const float m01 = fmaxf(acc[i][j][4 * g4 + 0], acc[i][j][4 * g4 + 1]), m23 = fmaxf(acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]);
                     out[(size_t)quad * a.Cout + n] = fmaxf(fmaxf(m01, m23) + bias, 0.0f);  // max(relu(v + b)) = relu(max(v) + b)
                 }
@@ -1629,28 +1638,39 @@ __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
         }
     } else {
         // weight fragment first: register 4 g4 + j of lane (r31, hh) is channel 8 g4 + 4 hh + j of the column block, row r31
-        // of the row block: four consecutive channels of one pixel = one 8-byte store
+        // of the row block: four consecutive channels of one pixel = one 8-byte LDS write into a wave-private 32-row x 128-byte
+        // tile, read back as whole 128-byte pixel lines, 16 bytes per lane (direct 8-byte stores cost 4.6 us per layer).
+        // The tile lives in brick buffer 0, whose last reader (step T - 4) every wave has left behind at barrier T - 1;
+        // chunk c of row r sits at slot c ^ (r & 7).
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        __bf16* const out = (__bf16*)a.out + (size_t)b * 196 * a.Cout;
+        __bf16* const stage = sBrick + wave * 32 * 64;  // 4 KB per wave
+        __bf16* const out = (__bf16*)a.out + (size_t)b * 196 * a.Cout + n0;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            if (i >= nrb) continue;
-            const int r = 32 * (wave + 4 * i) + r31, quad = r >> 2, qy = quad / 7, qx = quad - 7 * qy;
-            if (quad >= 49) continue;
-            const int y = 2 * qy + ((r >> 1) & 1), x = 2 * qx + (r & 1);
+            if (i >= nrb) continue;  // (wave-uniform)
+            const int qy = wave + 4 * i;
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int n = n0 + 32 * j + 8 * g4 + 4 * hh;
-                    const float4 bs = *(const float4*)(a.bias + n);
+                    const int n = 32 * j + 8 * g4 + 4 * hh;
+                    const float4 bs = *(const float4*)(a.bias + n0 + n);
                     bf16x4 v;
                     v.x = (__bf16)fmaxf(acc[i][j][4 * g4 + 0] + bs.x, 0.0f);
                     v.y = (__bf16)fmaxf(acc[i][j][4 * g4 + 1] + bs.y, 0.0f);
                     v.z = (__bf16)fmaxf(acc[i][j][4 * g4 + 2] + bs.z, 0.0f);
                     v.w = (__bf16)fmaxf(acc[i][j][4 * g4 + 3] + bs.w, 0.0f);
-                    *(bf16x4*)(out + (size_t)(y * 14 + x) * a.Cout + n) = v;
+                    *(bf16x4*)(stage + r31 * 64 + (((n >> 3) ^ (r31 & 7)) << 3) + (n & 4)) = v;
                 }
+            __builtin_amdgcn_wave_barrier();  // (wave-private tile: the wave's LDS writes are ordered before its reads)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {  // 32 rows x 8 chunks of 16 bytes = 256 lane-stores
+                const int ch = it * 64 + lane, r = ch >> 3, c8 = ch & 7, qx = r >> 2;
+                const uint4 v = *(const uint4*)(stage + r * 64 + ((c8 ^ (r & 7)) << 3));
+                const int y = 2 * qy + ((r >> 1) & 1), x = 2 * qx + (r & 1);
+                if (qx < 7) *(uint4*)(out + (size_t)(y * 14 + x) * a.Cout + 8 * c8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
