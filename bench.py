@@ -240,6 +240,9 @@ def main():
                          "run beside batch i + 1's TV-L1).  Measured SLOWER (216 vs 226 clips/s): the GPU is saturated, the "
                          "CNN has no idle CUs to hide in, and low-priority fragments disturb the two TV-L1 streams")
     ap.add_argument("--no-flow", action="store_true", help="CNN only on precomputed flow volumes (not the headline metric)")
+    ap.add_argument("--main-only", action="store_true",
+                    help="skip the legs after the timed region (tvl1_hd, roofline_cnn*, cpu_baseline): the profiler passes of "
+                         "tools/profile_bench.sh use it so that their per-kernel sums hold the benchmark's own launches only")
     ap.add_argument("--tvl1-params", default="", help="name=value,... overrides of va_tvl1_params (experiments)")
     args = ap.parse_args()
     if args.cpu_clips is not None and args.cpu_clips == 0:
@@ -363,7 +366,7 @@ def main():
             for l in per_level:
                 roof["ns_per_kpx_iter_l%d" % l["level"]] = l["ns_per_kpx_iter"]
         hd = cnn = cnn_bf16 = None
-        if world == 1:
+        if world == 1 and not args.main_only:
             hd = tvl1_hd_leg(args, dev)
             # CNN-only legs (outside the timed region): both VGG-16 streams on precomputed flow volumes
             # (a synthetic flow volume: the CNN's time does not depend on the values, and no TV-L1 work is added to the run)
@@ -377,7 +380,7 @@ def main():
             pipe2.close()
             cnn, cnn_bf16 = (cnn, leg2) if args.cnn_dtype == "f32" else (leg2, cnn)
         cpu = None
-        if world == 1 and args.cpu_pairs_per_core > 0:
+        if world == 1 and args.cpu_pairs_per_core > 0 and not args.main_only:
             cpu = cpu_baseline(args.cpu_pairs_per_core, tv_kw)
         line = {
             "metric": "clips/sec (224x224, RGB+10-flow two-stream)",
@@ -387,7 +390,7 @@ def main():
             "config": config, "roofline": roof, "tvl1_hd": hd, "roofline_cnn": cnn, "roofline_cnn_bf16": cnn_bf16, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if not (rank == 0 and world == 1):
+    if not (rank == 0 and world == 1 and not args.main_only):
         pipe.close()
     if world > 1:
         import torch.distributed as td
