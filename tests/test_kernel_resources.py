@@ -31,12 +31,15 @@ def test_every_default_kernel_is_free_of_vector_spills_and_scratch(kernels):
 def test_the_hot_kernels_keep_their_occupancy(kernels):
     by = {r["name"]: r for r in kernels}
     # two waves per SIMD for the row pipeline (<= 256 registers) in both forms; the two-group conv kernels too (512 threads)
-    for name, limit in (("k_iter_stream<2, 8, 2, false>", 256), ("k_iter_stream<2, 10, 1, false>", 256), ("k_conv3x3_pp_bf16<4, false>", 256),
-                        ("k_conv3x3_pp_bf16<4, true>", 256)):
+    # (and the one-image kernel of the 14 x 14 layers: four computing + four loader waves = two per SIMD)
+    for name, limit in (("k_iter_stream<2, 8, 2, false, 1>", 256), ("k_iter_stream<2, 10, 1, false, 1>", 256), ("k_conv3x3_pp_bf16<4, false>", 256),
+                        ("k_conv3x3_pp_bf16<4, true>", 256), ("k_conv3x3_img14_bf16<false>", 256), ("k_conv3x3_img14_bf16<true>", 256)):
         assert name in by, (name, sorted(by)[:5])
         assert by[name]["vgpr"] + by[name]["agpr"] <= limit, by[name]
     # four workgroups per CU for the tap-major bf16 kernel (<= 128 registers, <= 40 KB of LDS)
     for name in ("k_conv3x3_mfma_bf16<2, false, false, 1>", "k_conv3x3_mfma_bf16<2, true, false, 1>"):
         assert by[name]["vgpr"] + by[name]["agpr"] <= 128 and by[name]["lds"] <= 40960, by[name]
+    # the row pipeline: four two-wave jobs per CU (<= 40 KB of LDS each); the classifier's weight stream: >= 4 workgroups per CU
+    assert by["k_iter_stream<2, 8, 2, false, 1>"]["lds"] <= 40960 and by["k_fc_splitk"]["vgpr"] + by["k_fc_splitk"]["agpr"] <= 128
     # LDS budgets: one 160 KB CU
     assert max(r["lds"] for r in kernels) <= 163840
