@@ -206,7 +206,7 @@ static float divergence_at(const float* v1, const float* v2, int w, int h, int x
 long ora_tvl1_level(const float* I0, const float* I1, const float* I1x, const float* I1y,
                     int w, int h, const ora_tvl1_params* P, float* u1, float* u2)
 {
-    size_t n = (size_t)w * h, i;
+    size_t n = (size_t)w * h;
     float* buf = (float*)calloc(n * 10, sizeof(float));
     float *p11 = buf, *p12 = buf + n, *p21 = buf + 2 * n, *p22 = buf + 3 * n;
     float *wx = buf + 4 * n, *wy = buf + 5 * n, *rc = buf + 6 * n, *ig = buf + 7 * n;
@@ -217,14 +217,19 @@ long ora_tvl1_level(const float* I0, const float* I1, const float* I1x, const fl
     const int fixed = !(P->epsilon > 0.0f);
     const uint64_t qthr = fixed ? 0 : (uint64_t)((double)P->epsilon * (double)P->epsilon * (double)n * 4294967296.0);
     long total = 0;
-    int wp, it, x, y;
+    int wp, it;
+    /* Large frames called one pair at a time (the 1280x720 tests) spread the ROWS of a pass over the threads; inside the
+     * pair-parallel region of ora_tvl1_flow these inner regions are nested and run on one thread.  Every pixel of a pass
+     * is computed from the previous pass's arrays only and the error sum is an exact integer: results do not depend on it. */
+    const int par_rows = n >= 262144;
 
     for (wp = 0; wp < P->warps; wp++) {
         /* S5 */
-        for (y = 0; y < h; y++)
-            for (x = 0; x < w; x++) {
+#pragma omp parallel for schedule(static) if (par_rows)
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
                 float fxp, fyp, Iw, Iwx, Iwy, grad;
-                i = (size_t)y * w + x;
+                const size_t i = (size_t)y * w + x;
                 fxp = (float)x + u1[i]; fyp = (float)y + u2[i];
                 Iw = bilinear(I1, w, h, fxp, fyp);
                 Iwx = bilinear(I1x, w, h, fxp, fyp);
@@ -237,10 +242,11 @@ long ora_tvl1_level(const float* I0, const float* I1, const float* I1x, const fl
         /* S6, S7 */
         for (it = 0; it < P->iters; it++) {
             uint64_t qsum = 0;
-            for (y = 0; y < h; y++)
-                for (x = 0; x < w; x++) {
+#pragma omp parallel for schedule(static) reduction(+ : qsum) if (par_rows)
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) {
                     float rho, fi, v1, v2, a, b;
-                    i = (size_t)y * w + x;
+                    const size_t i = (size_t)y * w + x;
                     rho = fmaf(wy[i], u2[i], fmaf(wx[i], u1[i], rc[i]));
                     fi = fminf(fmaxf(-rho * ig[i], -l_t), l_t);
                     v1 = fmaf(fi, wx[i], u1[i]);
@@ -256,10 +262,11 @@ long ora_tvl1_level(const float* I0, const float* I1, const float* I1x, const fl
                 }
             memcpy(u1, n1, n * sizeof(float));
             memcpy(u2, n2, n * sizeof(float));
-            for (y = 0; y < h; y++)
-                for (x = 0; x < w; x++) {
+#pragma omp parallel for schedule(static) if (par_rows)
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) {
                     float u1x, u1y, u2x, u2y, d1, d2, rinv, r1, r2;
-                    i = (size_t)y * w + x;
+                    const size_t i = (size_t)y * w + x;
                     u1x = x < w - 1 ? u1[i + 1] - u1[i] : 0.0f;
                     u1y = y < h - 1 ? u1[i + w] - u1[i] : 0.0f;
                     u2x = x < w - 1 ? u2[i + 1] - u2[i] : 0.0f;
@@ -336,7 +343,7 @@ int ora_tvl1_flow(const float* frames, int n_seq, int frames_per_seq, int w, int
 #else
     (void)nthreads;
 #endif
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) if (npairs > 1) /* one pair: its rows are spread over the threads instead (ora_tvl1_level) */
     for (pi = 0; pi < npairs; pi++) {
         int sq = pi / (frames_per_seq - 1), k = pi % (frames_per_seq - 1), s;
         const float* f0 = frames + ((size_t)sq * frames_per_seq + k) * (size_t)w * h;
