@@ -76,6 +76,37 @@ def test_goldens():
         assert np.abs(g["logits_" + name][:1] - g["logits64_" + name]).max() < 1e-4
 
 
+def test_torch_oracle_against_the_independent_numpy_witness():
+    """oracle/vgg_witness_f64.py restates conv3x3 (cross-correlation, zero padding 1), 2x2 max-pooling, the C-order flatten
+    and the four Linear layers from their definitions in numpy float64; the torch oracle must agree with it -- in float64
+    to rounding, in float32 to the float32 noise of 13 + 4 layers -- through the whole layer list (32 x 32 input for the
+    conv stack: every conv layer and all five pools run, 1 x 1 x 512 at the end; the classifier on a full 25088 vector)."""
+    from oracle import vgg_witness_f64 as wit
+    assert wit.VGG16_D == vgg_oracle.VGG16_CFG
+    torch.set_num_threads(8)
+    for c_in, seed in ((3, 1), (20, 2)):
+        w = synth.synth_vgg16_weights(c_in=c_in, seed=seed)
+        if c_in != 3:
+            w["conv_w"][0] = vgg_oracle.copy_first_layer(w["conv_w"][0], c_in)
+        x = torch.from_numpy(synth.hash_uniform(60 + seed, 5, 2 * c_in * 32 * 32).reshape(2, c_in, 32, 32) * 4.0 - 2.0)
+        ref = wit.features(x.numpy(), [t.numpy() for t in w["conv_w"]], [t.numpy() for t in w["conv_b"]])
+        assert ref.shape == (2, 512, 1, 1) and np.abs(ref).max() > 0.1
+        with torch.no_grad():
+            f64 = vgg_oracle.features(x.double(), [t.double() for t in w["conv_w"]], [t.double() for t in w["conv_b"]]).numpy()
+            f32 = vgg_oracle.features(x, w["conv_w"], w["conv_b"]).numpy()
+        scale = np.abs(ref).max()
+        assert np.abs(f64 - ref).max() < 1e-12 * scale
+        assert np.abs(f32 - ref).max() < 1e-5 * scale
+        feat = torch.from_numpy(synth.hash_uniform(61 + seed, 6, 2 * 512 * 7 * 7).reshape(2, 512, 7, 7)).float()
+        d_ref, l_ref = wit.classifier(feat.numpy(), [t.numpy() for t in w["fc_w"]], [t.numpy() for t in w["fc_b"]])
+        with torch.no_grad():
+            d64, l64 = vgg_oracle.classifier(feat.double(), [t.double() for t in w["fc_w"]], [t.double() for t in w["fc_b"]])
+            d32, l32 = vgg_oracle.classifier(feat, w["fc_w"], w["fc_b"])
+        assert np.abs(d64.numpy() - d_ref).max() < 1e-11 * max(1.0, np.abs(d_ref).max())
+        assert np.abs(l64.numpy() - l_ref).max() < 1e-11 * max(1.0, np.abs(l_ref).max())
+        assert np.abs(l32.numpy() - l_ref).max() < 1e-4 and np.abs(d32.numpy() - d_ref).max() < 1e-4
+
+
 def test_training_oracle_reproduces_the_committed_golden():
     """First step of tests/golden/train_small.npz (autograd + torch.optim.SGD on 2 clips): pins the oracle to history."""
     import os
