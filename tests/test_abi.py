@@ -60,7 +60,7 @@ def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "video_analytics_amd")
     for dp, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".inc")):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), os.path.join(dp, f)
 

@@ -1258,366 +1258,7 @@ __global__ void __launch_bounds__(NWV * 64)
 }
 
 #ifdef VA_EXPERIMENTS  // measured-slower kernel families: k_iter_stream4, k_iter_stream_q, k_iter_rows
-// Four jobs per 512-thread workgroup (see stream_job, SUBS): gridDim.x workgroups cover a.njobs4 = 4 gridDim.x (>= jobs x
-// pairs) flattened jobs; the ones beyond the call's jobs are padding.
-template <bool FAST>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_iter_stream4(StreamArgs a, int jobs_per_pair, int njobs)
-{
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int sub = wave & 3, role = wave >> 2;
-    unsigned lid = blockIdx.x;
-    {
-        const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, xcd = lid % 8, kk = lid / 8;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
-        if (a.rev) lid = nb - 1 - lid;
-    }
-    const int j = (int)lid * 4 + sub;
-    const bool active = j < njobs;
-    const int jj = active ? j : 0;
-    // every job of the call has at most R + 2 K + 2 steps (rows of a chunk + its K-row halos + the pipeline depth + the wave boundary)
-    const int steps_pad = a.R + 3 * a.K + 2;
-    stream_job<2, 8, 2, FAST, 4>(a, a.pair0 + jj / jobs_per_pair, jj % jobs_per_pair, a.K, a.sin, a.sout, sub, role, active, steps_pad);
-}
-
-// k_iter_stream_q: ALL passes of a warp step in one launch, as a queue of tasks (pass, pair, strip, chunk) that
-// persistent workgroups pull in that order.  A launch per pass is a barrier across ALL pairs of the call every 16
-// iterations (20-43 per warp step): its tail (workgroups of different length, the last partial round of workgroups on
-// the CUs) leaves SIMDs without waves -- the counters show the inner-iteration waves VALU-active 48 % of their lifetime,
-// two per SIMD, yet the chip only 64 % VALU-busy.  Here a pair's pass n + 1 may start as soon as THAT pair's pass n is
-// complete (a per-pair, per-pass completion counter), so pairs drift apart freely and the only tail is the one at the end
-// of the warp step.
-//   * task id = atomicAdd on a head word; ids are handed out pass-major, so every task a workgroup can be waiting for
-//     is held by a workgroup that is running: no deadlock whatever the residency; spins are bounded (abort flag);
-//   * hand-over between workgroups on different CUs (MI355X_MICROARCH.md, inter-workgroup visibility): producer =
-//     every storing wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, lane 0: agent-scope release fence,
-//     drain, agent-scope atomic add on the pair's counter; consumer = lane 0 polls the counter with relaxed agent-scope
-//     loads, ONE agent-scope acquire fence, drain, workgroup barrier, then plain loads;
-//   * same arithmetic, same job decomposition and the same buffers as the launch-per-pass form: bit-identical results.
-struct StreamQArgs {
-    StreamArgs base;      // geometry, constants, ro; K / sin / sout / rev unused
-    float* st[2];         // the two state buffers
-    unsigned* ctl;        // ctl[0] = next task id, ctl[1] = abort flag, ctl[2 + pair * npass + pass] = finished tasks
-    int cur;              // buffer holding the input of pass 0
-    int npass, K, Klast;  // passes of K iterations, the last one Klast
-    int npairs, tpp;      // pairs of the call, tasks (strips x chunks) per pair and pass
-};
-template <int PPL, int KH, int NWV, bool FAST>
-__global__ void __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_iter_stream_q(StreamQArgs q)
-{
-    // Control flow around the barriers is WAVE-uniform (scalar branches on the wave index; the one lane that adds to a
-    // counter is selected by the VALUE it adds, not by a branch): a per-lane `if (threadIdx.x == 0)` next to a barrier
-    // inside this loop is restructured by the compiler so that the other 63 lanes of the wave run ahead to the next
-    // barrier -- the wave then executes more barriers than its partner and the workgroup hangs (reproduced in isolation).
-    __shared__ int s_task;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned one_lane = lane == 0 ? 1u : 0u;
-    const int per_pass = q.npairs * q.tpp, total = per_pass * q.npass;
-    for (;;) {
-        if (wv == 0) {
-            int id = __builtin_amdgcn_readfirstlane((int)__hip_atomic_fetch_add(&q.ctl[0], one_lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (id < total && id >= per_pass) {
-                // wait for this pair's previous pass: all its tasks were handed out before this one
-                const int n = id / per_pass, pr = (id - n * per_pass) / q.tpp;
-                const unsigned* cnt = &q.ctl[2 + pr * q.npass + (n - 1)];
-                int spins = 0;
-                while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < q.tpp) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 22) ||
-                        __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&q.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) {
-                        __hip_atomic_store(&q.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // give up: never hang the GPU
-                        id = total;
-                        break;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            s_task = id;
-        }
-        __syncthreads();
-        const int id = __builtin_amdgcn_readfirstlane(s_task);  // uniform: the job's geometry stays in scalar registers
-        if (id >= total) return;
-        const int n = id / per_pass, rem = id - n * per_pass, pr = rem / q.tpp, job = rem - pr * q.tpp;
-        const int in = (q.cur ^ n) & 1;
-        float* const sin = in ? q.st[1] : q.st[0];
-        float* const sout = in ? q.st[0] : q.st[1];
-        stream_job<PPL, KH, NWV, FAST>(q.base, q.base.pair0 + pr, job, n == q.npass - 1 ? q.Klast : q.K, sin, sout);
-        // publish: every wave's stores have left, then one release + one counter add for the workgroup
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (wv == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(&q.ctl[2 + pr * q.npass + n], one_lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-// ---------------------------------------------------------------- persistent row pipeline ------
-//
-// k_iter_rows: ALL `iters` inner iterations of one warp step in ONE launch, for levels that fit a single strip
-// (pitch <= 64 * PPL columns, PPL = 2, 3 or 4 pixels per lane: no x halo at all).  One workgroup owns one pair; its NWV
-// waves form the time-skewed row pipeline of k_iter_stream (wave W holds levels W*KH .. W*KH + KH - 1, rows are handed
-// from wave to wave through a double-buffered LDS row, one LDS-only barrier per step), but the pipeline never drains
-// between passes: the rows of pass n + 1 (read back from the buffer pass n wrote, K = NWV*KH iterations earlier in
-// time) follow the last row of pass n immediately, so the triangular fill/drain of a pass is paid once per launch
-// instead of once per K iterations, and there is no y halo and no launch boundary inside a warp step.
-//
-//  * Row identity travels with the row as one scalar: id = pass << 20 | ring slot << 14 | row (-1 = no row).  A level
-//    that holds a row emits it (one iteration on) when the next row arrives and keeps the arrival; a level that is not
-//    active for a row (its index >= the pass's depth) hands it on untouched.  Everything about identity is SALU work.
-//  * iters = K0 + (N - 1) K with the SHORT pass first: levels >= K0 are inactive for pass 0 and still hold their
-//    zero-initialised state when pass 1 reaches them, exactly as at the start of the kernel.
-//  * The image's last row is flushed by whatever row follows it (row 0 of the next pass, or dummy rows after the
-//    last pass): its forward y difference is multiplied by my = 0 whenever the arriving row has index 0.  A level in
-//    its initial state emits an exact zero row with no identity, which nobody stores.
-//  * Pass n + 1 reads row r at least h - K - NWV - 2 steps after pass n stored it; both happen on the same CU (one
-//    workgroup), whose vector L1 is write-through and coherent for its own waves: the storing wave drains its older
-//    stores (s_waitcnt vmcnt) before each step's barrier, nothing else is needed (no agent-scope fence).
-//  * The per-warp constants of the K + NWV rows in flight sit in an LDS ring written by the loading wave.
-// Same arithmetic as k_iter_tile / k_iter_stream, operation for operation: results are bit-identical.
-struct RowsArgs {
-    const float* ro;
-    float* st;            // the lower of the two state buffers (pair-major planes)
-    unsigned delta[2];    // byte offset of state buffer 0 / 1 from `st`
-    size_t plane;
-    int w, h, pitch;
-    int K, K0, N;         // iterations of a full pass (<= NWV*KH), of the first pass (1..K), number of passes
-    int cur;              // buffer index holding the input of pass 0
-    int pair0;
-    float l_t, taut, theta;
-};
-
-constexpr int kRowIdRowBits = 14, kRowIdSlotBits = 6;  // id = pass << 20 | slot << 14 | row
-
-template <int PPL, int KH, int NWV, bool FAST>
-__global__ void __launch_bounds__(NWV * 64) k_iter_rows(RowsArgs a)
-{
-    typedef Row<PPL> R;
-    constexpr int NP = R::NP, NT = R::NT, KMAX = KH * NWV, NRING = KMAX + NWV, NB = NWV > 1 ? NWV - 1 : 1;
-    static_assert(NRING <= (1 << kRowIdSlotBits), "ring slots must fit the row identity");
-    __shared__ f2 ringP[NRING][kNF_RO][NP][64];
-    __shared__ float ringT[NRING][kNF_RO][NT ? 64 : 1];
-    __shared__ f2 ifP[NB][2][kNF_STATE][NP][64];
-    __shared__ float ifT[NB][2][kNF_STATE][NT ? 64 : 1];
-    __shared__ int ifId[NB][2];
-
-    const int pair = a.pair0 + (int)blockIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int wv = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int w = a.w, h = a.h, pitch = a.pitch, K = a.K, K0 = a.K0, NPASS = a.N;
-    const int x0 = PPL * lane;
-    const bool colok = x0 < pitch;  // the pitch is a multiple of PPL: a lane is wholly inside a row or wholly outside
-    const int loff = colok ? x0 * (int)sizeof(float) : 0;
-    const int planeb = (int)(a.plane * sizeof(float)), pitchb = pitch * (int)sizeof(float);
-    const unsigned dmax = a.delta[0] > a.delta[1] ? a.delta[0] : a.delta[1];
-    const __amdgpu_buffer_rsrc_t rs_ro = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.ro + (size_t)pair * kNF_RO * a.plane), 0, kNF_RO * planeb, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc(
-        a.st + (size_t)pair * kNF_STATE * a.plane, 0, (int)dmax + kNF_STATE * planeb, 0x00020000);
-
-    R mx;
-    mx.t = 0.0f;
-#pragma clang loop unroll(full)
-    for (int i = 0; i < PPL; ++i) row_set(mx, i, x0 + i < w - 1 ? 1.0f : 0.0f);
-    const float l_t = a.l_t, taut = a.taut, theta = a.theta;
-    const R zero = row_splat<PPL>(0.0f);
-
-    if constexpr (NWV > 1) {
-        if (wv < NWV - 1) {
-#pragma clang loop unroll(full)
-            for (int b = 0; b < 2; ++b) {
-#pragma clang loop unroll(full)
-                for (int f = 0; f < kNF_STATE; ++f) {
-#pragma clang loop unroll(full)
-                    for (int j = 0; j < NP; ++j) ifP[wv][b][f][j][lane] = splat(0.0f);
-                    if constexpr (NT) ifT[wv][b][f][lane] = 0.0f;
-                }
-                if (lane == 0) ifId[wv][b] = -1;
-            }
-        }
-        __syncthreads();
-    }
-
-    R P11[KH], P12[KH], P21[KH], P22[KH], U1[KH], U2[KH];
-    int sid[KH];
-#pragma clang loop unroll(full)
-    for (int t = 0; t < KH; ++t) {
-        P11[t] = P12[t] = P21[t] = P22[t] = U1[t] = U2[t] = zero;
-        sid[t] = -1;
-    }
-
-    // loader (wave 0): the row of the current step and the prefetched data of that row
-    int ln = 0, lr = 0, lslot = 0;
-    R nst[kNF_STATE], nro[kNF_RO];
-#pragma clang loop unroll(full)
-    for (int f = 0; f < kNF_STATE; ++f) nst[f] = zero;
-#pragma clang loop unroll(full)
-    for (int f = 0; f < kNF_RO; ++f) nro[f] = zero;
-    if (wv == 0) {
-        const int so = (int)a.delta[a.cur & 1];
-#pragma clang loop unroll(full)
-        for (int f = 0; f < kNF_STATE; ++f) nst[f] = row_load<PPL>(rs_st, loff, so + f * planeb);
-#pragma clang loop unroll(full)
-        for (int f = 0; f < kNF_RO; ++f) nro[f] = row_load<PPL>(rs_ro, loff, f * planeb);
-    }
-
-    const int nsteps = NPASS * h + KMAX + NWV + 1;
-    for (int s = 0; s < nsteps; ++s) {
-        R c[kNF_STATE];
-        int ids[KH + 1];
-        if (wv == 0) {
-#pragma clang loop unroll(full)
-            for (int f = 0; f < kNF_STATE; ++f) c[f] = nst[f];
-            ids[0] = (ln << (kRowIdRowBits + kRowIdSlotBits)) | (lslot << kRowIdRowBits) | lr;
-#pragma clang loop unroll(full)
-            for (int f = 0; f < kNF_RO; ++f) {
-#pragma clang loop unroll(full)
-                for (int j = 0; j < NP; ++j) ringP[lslot][f][j][lane] = nro[f].p[j];
-                if constexpr (NT) ringT[lslot][f][lane] = nro[f].t;
-            }
-            // the next row: row 0 of the next pass after row h - 1; after the last pass dummy rows (the last pass's input
-            // row h - 1 again: finite values) that only push the last rows through the levels
-            int nn = ln, nr = lr + 1;
-            if (nn < NPASS && nr == h) {
-                nr = 0;
-                ++nn;
-            }
-            const int pn = nn < NPASS ? nn : NPASS - 1, pr = nn < NPASS ? nr : h - 1;
-            const int so = (int)a.delta[(a.cur ^ pn) & 1] + pr * pitchb;
-#pragma clang loop unroll(full)
-            for (int f = 0; f < kNF_STATE; ++f) nst[f] = row_load<PPL>(rs_st, loff, so + f * planeb);
-#pragma clang loop unroll(full)
-            for (int f = 0; f < kNF_RO; ++f) nro[f] = row_load<PPL>(rs_ro, loff, pr * pitchb + f * planeb);
-            ln = nn;
-            lr = nr;
-            lslot = lslot + 1 == NRING ? 0 : lslot + 1;
-            __builtin_amdgcn_sched_barrier(0);  // the loads stay at the top of the step: a whole step hides their latency
-        } else {
-            const int b = (s + 1) & 1, wb = wv - 1;  // what the wave before wrote in step s - 1
-#pragma clang loop unroll(full)
-            for (int f = 0; f < kNF_STATE; ++f) {
-#pragma clang loop unroll(full)
-                for (int j = 0; j < NP; ++j) c[f].p[j] = ifP[wb][b][f][j][lane];
-                c[f].t = 0.0f;
-                if constexpr (NT) c[f].t = ifT[wb][b][f][lane];
-            }
-            ids[0] = __builtin_amdgcn_readfirstlane(ifId[wb][b]);
-        }
-        // identity pre-pass (scalar): which levels of this wave work in this step, on which rows
-        bool act[KH];
-#pragma clang loop unroll(full)
-        for (int t = 0; t < KH; ++t) {
-            const int in = ids[t];
-            const int kof = (in >> (kRowIdRowBits + kRowIdSlotBits)) == 0 ? K0 : K;
-            act[t] = in >= 0 && wv * KH + t < kof;
-            ids[t + 1] = act[t] ? sid[t] : in;
-            sid[t] = act[t] ? in : sid[t];
-        }
-        auto consts = [&](int t, R (&q)[kNF_RO]) __attribute__((always_inline)) {
-            const int slot = act[t] ? (ids[t] >> kRowIdRowBits) & ((1 << kRowIdSlotBits) - 1) : 0;
-#pragma clang loop unroll(full)
-            for (int f = 0; f < kNF_RO; ++f) {
-#pragma clang loop unroll(full)
-                for (int j = 0; j < NP; ++j) q[f].p[j] = ringP[slot][f][j][lane];
-                q[f].t = 0.0f;
-                if constexpr (NT) q[f].t = ringT[slot][f][lane];
-            }
-        };
-        R q[kNF_RO];
-        consts(0, q);
-#pragma clang loop unroll(full)
-        for (int t = 0; t < KH; ++t) {
-            R nq[kNF_RO];
-            if (t + 1 < KH) {
-                consts(t + 1 < KH ? t + 1 : 0, nq);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (act[t]) {
-                // phase A on the arriving row (time t), phase B on the row the level holds (its lower neighbour is the
-                // row just computed); the level keeps the arriving p and the new u and emits (old u, new p) = the held row
-                // one iteration on.  k_iter_tile's arithmetic, operation for operation.
-                const float my = (ids[t] & ((1 << kRowIdRowBits) - 1)) != 0 ? 1.0f : 0.0f;
-                const R &wx = q[0], &wy = q[1], &rc = q[2], &ig = q[3];
-                const R dx11 = r_diff_back(c[2]), dx21 = r_diff_back(c[4]);
-                const R div1 = r_add(dx11, r_sub(c[3], P12[t]));
-                const R div2 = r_add(dx21, r_sub(c[5], P22[t]));
-                const R rho = r_fma(wy, c[1], r_fma(wx, c[0], rc));
-                const R tt = r_negmul(rho, ig);
-                const R fi = r_med3(tt, -l_t, l_t);
-                const R v1 = r_fma(fi, wx, c[0]);
-                const R v2 = r_fma(fi, wy, c[1]);
-                const R n1 = r_fma_s(theta, div1, v1);
-                const R n2 = r_fma_s(theta, div2, v2);
-                const R d1x = r_diff_fwd(U1[t]), d2x = r_diff_fwd(U2[t]);
-                const R u1x = r_mul(d1x, mx), u1y = r_mul_s(r_sub(n1, U1[t]), my);
-                const R u2x = r_mul(d2x, mx), u2y = r_mul_s(r_sub(n2, U2[t]), my);
-                const R s1 = r_fma(u1y, u1y, r_fma_c(u1x, u1x, kSqrtReg));
-                const R s2 = r_fma(u2y, u2y, r_fma_c(u2x, u2x, kSqrtReg));
-                R q1, q2;
-                if constexpr (FAST) {
-                    const R d1 = r_fma_s(taut, r_sqrt<PPL, true>(s1), row_splat<PPL>(1.0f));
-                    const R d2 = r_fma_s(taut, r_sqrt<PPL, true>(s2), row_splat<PPL>(1.0f));
-                    q1 = r_rcp<PPL, true>(d1);
-                    q2 = r_rcp<PPL, true>(d2);
-                } else {
-                    const R d1 = r_fma_s(taut, r_sqrt<PPL, false>(s1), row_splat<PPL>(1.0f));
-                    const R d2 = r_fma_s(taut, r_sqrt<PPL, false>(s2), row_splat<PPL>(1.0f));
-                    const R rinv = r_rcp<PPL, false>(r_mul(d1, d2));
-                    q1 = r_mul(d2, rinv);
-                    q2 = r_mul(d1, rinv);
-                }
-                const R o11 = r_mul(r_fma_s(taut, u1x, P11[t]), q1);
-                const R o12 = r_mul(r_fma_s(taut, u1y, P12[t]), q1);
-                const R o21 = r_mul(r_fma_s(taut, u2x, P21[t]), q2);
-                const R o22 = r_mul(r_fma_s(taut, u2y, P22[t]), q2);
-                const R ou1 = U1[t], ou2 = U2[t];
-                P11[t] = c[2];
-                P12[t] = c[3];
-                P21[t] = c[4];
-                P22[t] = c[5];
-                U1[t] = n1;
-                U2[t] = n2;
-                c[0] = ou1;
-                c[1] = ou2;
-                c[2] = o11;
-                c[3] = o12;
-                c[4] = o21;
-                c[5] = o22;
-            }
-            if (t + 1 < KH) {
-#pragma clang loop unroll(full)
-                for (int f = 0; f < kNF_RO; ++f) q[f] = nq[f];
-            }
-        }
-        const int out = ids[KH];
-        if (NWV > 1 && wv < NWV - 1) {
-            const int b = s & 1;
-#pragma clang loop unroll(full)
-            for (int f = 0; f < kNF_STATE; ++f) {
-#pragma clang loop unroll(full)
-                for (int j = 0; j < NP; ++j) ifP[wv][b][f][j][lane] = c[f].p[j];
-                if constexpr (NT) ifT[wv][b][f][lane] = c[f].t;
-            }
-            if (lane == 0) ifId[wv][b] = out;
-        } else {
-            const int on = out >> (kRowIdRowBits + kRowIdSlotBits);
-            if (out >= 0 && on < NPASS && colok) {
-                const int so = (int)a.delta[(a.cur ^ (on + 1)) & 1] + (out & ((1 << kRowIdRowBits) - 1)) * pitchb;
-#pragma clang loop unroll(full)
-                for (int f = 0; f < kNF_STATE; ++f) row_store<PPL>(c[f], rs_st, loff, so + f * planeb);
-            }
-        }
-        if constexpr (NWV > 1) {
-            // The storing wave drains every store older than this step's (the next pass reads them back, h - K - NWV - 2
-            // steps from now at the earliest); then the hand-over barrier: LDS traffic only.
-            if (wv == NWV - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kNF_STATE) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-    }
-}
-
+#include "tvl1_experiments.inc"
 #endif  // VA_EXPERIMENTS
 
 // ---------------------------------------------------------------- host side -------------------
@@ -2346,6 +1987,8 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                     if (p->fast_math) k_iter_stream_q<2, kStreamKH2, 2, true><<<nwg, 128, 0, st>>>(qa);
                     else k_iter_stream_q<2, kStreamKH2, 2, false><<<nwg, 128, 0, st>>>(qa);
                     VA_LAUNCH_CHECK();
+                    k_poison_if_aborted<<<nc, 64, 0, st>>>(ctl, state[0] + (size_t)c0 * kNF_STATE * plane, state[1] + (size_t)c0 * kNF_STATE * plane,
+                                                            (size_t)kNF_STATE * plane, lw);
                     cur ^= qn & 1;
                     launches = 1;
                 }
