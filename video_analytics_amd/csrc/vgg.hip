@@ -1431,7 +1431,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_ws_bf16(ConvArgsWs a)
 // runs them as 392 workgroups of 128 pixels x 64 channels that stage, per 64-channel K step, a fresh copy of the activations
 // for every one of the nine taps and every one of the eight channel tiles: 462 MB of activation staging + 231 MB of weights
 // per layer at batch 32, which at the measured 27-29 B/clk a CU takes in is its 51-54 us (23 % of the matrix pipe).
-// k_conv3x3_img14_bf16 gives every workgroup ONE WHOLE IMAGE and 64 output channels (batch 32: 32 x 8 = 256 workgroups, one
+// k_conv3x3_img14 gives every workgroup ONE WHOLE IMAGE and 64 output channels (batch 32: 32 x 8 = 256 workgroups, one
 // per CU, one round):
 //   * the image's 64-channel chunk is staged ONCE as a zero-bordered 16 x 16 halo brick (32 KB, double-buffered); the nine
 //     taps are formed by shifting the brick pixel a fragment row reads -- 1/9 of the activation staging, and 1/8 of it
@@ -1449,32 +1449,46 @@ __global__ void __launch_bounds__(256) k_conv3x3_ws_bf16(ConvArgsWs a)
 //   * K order is chunk-major (64-channel chunk outside, tap inside): another fp32 summation order than the tap-major
 //     kernels, so its results agree with theirs at the bf16 noise level, not bit for bit (like the first-layer paths).
 // POOLF32 = false: bf16 NHWC output (conv5_1, conv5_2); true: bias + ReLU + 2 x 2 max-pool, fp32 NHWC [B][7][7][Cout] (conv5_3).
-// TIMING BUILDS ONLY (wrong results): parts of k_conv3x3_img14_bf16's steps to leave out -- 1 = the MFMAs, 2 = the fragment
+// TIMING BUILDS ONLY (wrong results): parts of k_conv3x3_img14's steps to leave out -- 1 = the MFMAs, 2 = the fragment
 // reads, 4 = the LDS-DMA refills inside the loop
 #ifndef VA_I14_SKIP
 #define VA_I14_SKIP 0
 #endif
-template <bool POOLF32>
-__device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
+struct Img14Args {
+    const void* in;     // NHWC [B][14][14][Cin] of T, Cin % (128 / sizeof(T)) == 0
+    const void* wp;     // [Cout][9][Cin] of T
+    const float* bias;  // [Cout]
+    void* out;          // NHWC [B][14][14][Cout] of T, or pooled f32 [B][7][7][Cout] when POOL
+    int B, Cin, Cout;
+};
+
+// T = __bf16 (chunk = 64 channels, v_mfma_f32_32x32x16_bf16) or float (chunk = 32 channels, v_mfma_f32_32x32x2_f32: the fp32
+// parity path, round 3): a pixel's chunk is one 128-byte line either way, so bricks, weight tiles, DMA pieces, swizzles and
+// fragment addresses are the same; a 16-byte fragment is 8 bf16 for one MFMA or 4 floats for four.
+template <typename T, bool POOL>
+__device__ __forceinline__ void conv3x3_img14_body(const Img14Args& a)
 {
-    // one step = one kernel ROW (three taps) of one 64-channel chunk: 48 MFMAs per computing wave between two barriers
-    constexpr int BRICK = 256 * kBfBK, WT = 3 * 64 * kBfBK, NWR = 3;  // bf16 elements: halo brick chunk, weight tile (3 taps); ring depth
-    constexpr int WPIECES = 6, BPIECES = 8;                            // a loader wave's 1 KB DMA pieces per weight tile / per brick chunk
-    __shared__ __attribute__((aligned(1024))) __bf16 smem[2 * BRICK + NWR * WT];
-    __bf16* const sBrick = smem;
-    __bf16* const sW = smem + 2 * BRICK;
+    constexpr bool F32 = sizeof(T) == 4;
+    constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+    constexpr int BK = 8 * EPC;               // channels per chunk: one 128-byte line per pixel
+    // one step = one kernel ROW (three taps) of one chunk: 48 (bf16) / 192 (fp32) MFMAs per computing wave between two barriers
+    constexpr int BRICK = 256 * BK, WT = 3 * 64 * BK, NWR = 3;  // elements: halo brick chunk, weight tile (3 taps); ring depth
+    constexpr int WPIECES = 6, BPIECES = 8;                      // a loader wave's 1 KB DMA pieces per weight tile / per brick chunk
+    __shared__ __attribute__((aligned(1024))) T smem[2 * BRICK + NWR * WT];
+    T* const sBrick = smem;
+    T* const sW = smem + 2 * BRICK;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3: computing waves, 4..7: loader waves (one of each per SIMD)
     const int wave = wave8 & 3;
     const int tiles_n = a.Cout / 64;
     // Workgroup id -> (channel tile, image): consecutive ids go round-robin over the 8 XCDs, so with id % tiles_n as the
-    // channel tile (8 tiles at 512 channels) every XCD works on ONE 64-channel slice of the weights (0.59 MB: resident in
+    // channel tile (8 tiles at 512 channels) every XCD works on ONE 64-channel slice of the weights (0.59 / 1.18 MB: resident in
     // its L2, read by the XCD's 32 workgroups) -- the weight tile a step waits for then comes from L2, while the image
     // bricks, which are fetched a whole chunk ahead, may come from further away.
     const int n_tile = blockIdx.x % tiles_n, b = blockIdx.x / tiles_n;
     const int n0 = n_tile * 64, Cin = a.Cin;
     const int r31 = lane & 31, hh = lane >> 5, lrow = lane >> 3, lslot = lane & 7;
-    const int nchunks = Cin / kBfBK, T = 3 * nchunks;
+    const int nchunks = Cin / BK, NT_STEPS = 3 * nchunks;
     // Brick pixel bp = 16 by + bx holds image pixel (by - 1, bx - 1), zeros on the border; its 16-byte chunk c sits at slot
     // c ^ swz(bp) of its 128-byte line (swizzle on the source side, as above).  A fragment read's 16-lane groups hold four
     // 2 x 2 quads: the pixels of a quad's two rows are 16 brick pixels = 2 KB apart, i.e. on the same banks, so the swizzle
@@ -1488,50 +1502,52 @@ __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
         // pipe 33 % busy).  Here they belong to a wave of their own on every SIMD, which does nothing else: it refills the
         // ring behind the barrier, waits for its pieces of the NEXT step to land, and meets the computing waves at the
         // next barrier -- its arrival is what tells them the tile is complete.
+        const T* const in = (const T*)a.in;
+        const T* const wp = (const T*)a.wp;
         const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<__bf16*>(a.in) + (size_t)b * 196 * Cin, 0, 196 * Cin * 2, 0x00020000);
+            const_cast<T*>(in) + (size_t)b * 196 * Cin, 0, 196 * Cin * (int)sizeof(T), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<__bf16*>(a.wp) + (size_t)n0 * 9 * Cin, 0, 64 * 9 * Cin * 2, 0x00020000);
+            const_cast<T*>(wp) + (size_t)n0 * 9 * Cin, 0, 64 * 9 * Cin * (int)sizeof(T), 0x00020000);
         int aoff[BPIECES];  // brick pixels (8 wave + i) * 8 + lrow
 #pragma unroll
         for (int i = 0; i < BPIECES; ++i) {
             const int bp = ((wave * 8 + i) << 3) + lrow, by = bp >> 4, bx = bp & 15;
             const bool ok = by >= 1 && by <= 14 && bx >= 1 && bx <= 14;
-            aoff[i] = ok ? (((by - 1) * 14 + (bx - 1)) * Cin + 8 * (lslot ^ brick_swz(bp))) * 2 : 0x7fffffff;  // out of range: zeros
+            aoff[i] = ok ? (((by - 1) * 14 + (bx - 1)) * Cin + EPC * (lslot ^ brick_swz(bp))) * (int)sizeof(T) : 0x7fffffff;  // out of range: zeros
         }
-        int boff[2];  // output channels (2 wave + i) * 8 + lrow of a tap's 64 x 64 sub-tile
+        int boff[2];  // output channels (2 wave + i) * 8 + lrow of a tap's 64 x BK sub-tile
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (wave * 2 + i) * 8 + lrow;
-            boff[i] = (row * 9 * Cin + 8 * (lslot ^ ((row >> 1) & 7))) * 2;
+            boff[i] = (row * 9 * Cin + EPC * (lslot ^ ((row >> 1) & 7))) * (int)sizeof(T);
         }
         auto stage_brick = [&](int chunk) {
-            __bf16* const dst = sBrick + (chunk & 1) * BRICK;
+            T* const dst = sBrick + (chunk & 1) * BRICK;
             static_for<BPIECES>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(dst + (wave * 8 + i) * 8 * kBfBK), 16, aoff[i], chunk * kBfBK * 2, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(dst + (wave * 8 + i) * 8 * BK), 16, aoff[i], chunk * BK * (int)sizeof(T), 0, 0);
             });
         };
-        auto stage_w = [&](int t) {  // step t = 3 chunk + ky: weights [n][3 ky + kx][chunk * 64 ..], kx = 0, 1, 2
+        auto stage_w = [&](int t) {  // step t = 3 chunk + ky: weights [n][3 ky + kx][chunk * BK ..], kx = 0, 1, 2
             const int chunk = t / 3, ky = t - 3 * chunk;
-            __bf16* const dst = sW + (t % NWR) * WT;
+            T* const dst = sW + (t % NWR) * WT;
             static_for<WPIECES>([&](auto I) {
                 constexpr int i = decltype(I)::value, kx = i >> 1, h = i & 1;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(dst + kx * 64 * kBfBK + (wave * 2 + h) * 8 * kBfBK), 16, boff[h],
-                                                         ((3 * ky + kx) * Cin + chunk * kBfBK) * 2, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(dst + kx * 64 * BK + (wave * 2 + h) * 8 * BK), 16, boff[h],
+                                                         ((3 * ky + kx) * Cin + chunk * BK) * (int)sizeof(T), 0, 0);
             });
         };
         // prologue: brick 0, weight tiles of steps 0 and 1
         stage_brick(0);
         stage_w(0);
-        if (T > 1) stage_w(1);
+        if (NT_STEPS > 1) stage_w(1);
         bool brick_prev = false;  // a brick was issued in the previous step (it sits in the queue BEFORE that step's weight tile)
-        for (int t = 0; t < T; ++t) {
+        for (int t = 0; t < NT_STEPS; ++t) {
             const int chunk = t / 3, ky = t - 3 * chunk;
             // this wave's pieces of step t must have landed; younger ones may fly: the weight tile of step t + 1 (6 pieces) and,
             // when a brick was issued in the step before (after tile t, before tile t + 1), its 8 pieces
             // (queue at this point, oldest first: tile t | [brick, 8 pieces] | tile t + 1, 6 pieces)
-            if (t + 1 >= T) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t + 1 >= NT_STEPS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (brick_prev) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // step t is complete in LDS; the computing waves have read step t - 1
@@ -1539,7 +1555,7 @@ __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
             // weight tile of step t + 2 (its slot held step t - 1)
             brick_prev = ky == 0 && chunk + 1 < nchunks && !(VA_I14_SKIP & 4);
             if (brick_prev) stage_brick(chunk + 1);
-            if (t + 2 < T && !(VA_I14_SKIP & 4)) stage_w(t + 2);
+            if (t + 2 < NT_STEPS && !(VA_I14_SKIP & 4)) stage_w(t + 2);
         }
         return;
     }
@@ -1548,6 +1564,7 @@ __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
     // fragment rows: row blocks wave and wave + 4 (wave 3's second block is the dummy block 7: all rows read the brick's
     // zero corner; its MFMAs cost nothing the other waves do not spend anyway)
     constexpr int MT = 2, NT = 2;
+    typedef typename std::conditional<F32, f32x4, bf16x8>::type frag_t;
     const int nrb = wave < 3 ? 2 : 1;
     int bp0[MT];  // centre-tap brick pixel of this lane's row in each block (0 = rows beyond the image: the zero corner pixel)
 #pragma unroll
@@ -1564,14 +1581,25 @@ __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const int fsw = (r31 >> 1) & 7;
+    // pixel fragment first (rows of the accumulator = pixels: a register quad is a pooling window) when pooling; weight
+    // fragment first (rows = channels: four consecutive channels of one pixel per register quad) otherwise
+    auto mma = [&](const frag_t& fpix, const frag_t& fwgt, f32x16& c) __attribute__((always_inline)) {
+        if constexpr (F32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                c = POOL ? __builtin_amdgcn_mfma_f32_32x32x2f32(fpix[e], fwgt[e], c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(fwgt[e], fpix[e], c, 0, 0, 0);
+        } else {
+            c = POOL ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fpix, fwgt, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwgt, fpix, c, 0, 0, 0);
+        }
+    };
 
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < NT_STEPS; ++t) {
         const int chunk = t / 3, ky = t - 3 * chunk;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // the loader waves have seen step t land; every computing wave has read step t - 1
-        const __bf16* const sA = sBrick + (chunk & 1) * BRICK;
-        const __bf16* const sB = sW + (t % NWR) * WT;
-        // Six sub-steps (3 taps x 2 halves of the 64 channels) of 8 MFMAs, branch-free and fully unrolled; the 8 fragment reads
+        const T* const sA = sBrick + (chunk & 1) * BRICK;
+        const T* const sB = sW + (t % NWR) * WT;
+        // Six sub-steps (3 taps x 2 halves of the chunk) of 8 fragment pairs, branch-free and fully unrolled; the 8 fragment reads
         // of sub-step s + 1 are ISSUED BEFORE the MFMAs of sub-step s (sched_barrier pins that order) and waited for only at
         // the start of s + 1: with one computing wave per SIMD nothing else covers the LDS latency.
         int arow[3][MT], asw[3][MT];
@@ -1580,20 +1608,20 @@ __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int bp = bp0[i] ? bp0[i] + (ky - 1) * 16 + (kx - 1) : 0;
-                arow[kx][i] = bp * kBfBK;
+                arow[kx][i] = bp * BK;
                 asw[kx][i] = brick_swz(bp);
             }
-        bf16x8 fa[2][2][MT], fb[2][2][NT];  // [buffer][half of the sub-step][block]
+        frag_t fa[2][2][MT], fb[2][2][NT];  // [buffer][half of the sub-step][block]
         auto fetch = [&](auto SS, auto BUF) {
             constexpr int ss = decltype(SS)::value, kx = ss >> 1, bf = decltype(BUF)::value;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int ks = 2 * (ss & 1) + h;
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[bf][h][i] = *reinterpret_cast<const bf16x8*>(&sA[arow[kx][i] + (((2 * ks + hh) ^ asw[kx][i]) << 3)]);
+                for (int i = 0; i < MT; ++i) fa[bf][h][i] = *reinterpret_cast<const frag_t*>(&sA[arow[kx][i] + (((2 * ks + hh) ^ asw[kx][i]) * EPC)]);
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    fb[bf][h][j] = *reinterpret_cast<const bf16x8*>(&sB[kx * 64 * kBfBK + (j * 32 + r31) * kBfBK + (((2 * ks + hh) ^ fsw) << 3)]);
+                    fb[bf][h][j] = *reinterpret_cast<const frag_t*>(&sB[kx * 64 * BK + (j * 32 + r31) * BK + (((2 * ks + hh) ^ fsw) * EPC)]);
             }
         };
         fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -1607,15 +1635,13 @@ __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = POOLF32 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][h][i], fb[cur][h][j], acc[i][j], 0, 0, 0)
-                                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][h][j], fa[cur][h][i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) mma(fa[cur][h][i], fb[cur][h][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         });
     }
 
-    // ---- epilogue, straight from the accumulators (25 KB of output per workgroup against 0.85 MB staged)
-    if constexpr (POOLF32) {
+    // ---- epilogue
+    if constexpr (POOL) {
         // pixel fragment first: register 4 g4 + j of lane (r31, hh) is row 8 g4 + 4 hh + j of the block, channel r31 of the
         // column block: the four registers are one quad = one pooling window
         float* const out = (float*)a.out + (size_t)b * 49 * a.Cout;
@@ -1638,13 +1664,13 @@ __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
         }
     } else {
         // weight fragment first: register 4 g4 + j of lane (r31, hh) is channel 8 g4 + 4 hh + j of the column block, row r31
-        // of the row block: four consecutive channels of one pixel = one 8-byte LDS write into a wave-private 32-row x 128-byte
-        // tile, read back as whole 128-byte pixel lines, 16 bytes per lane (direct 8-byte stores cost 4.6 us per layer).
+        // of the row block: four consecutive channels of one pixel = one 8-/16-byte LDS write into a wave-private 32-row x 64-channel
+        // tile, read back as whole pixel lines, 16 bytes per lane (direct 8-byte stores cost 4.6 us per layer).
         // The tile lives in brick buffer 0, whose last reader (step T - 4) every wave has left behind at barrier T - 1;
-        // chunk c of row r sits at slot c ^ (r & 7).
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        __bf16* const stage = sBrick + wave * 32 * 64;  // 4 KB per wave
-        __bf16* const out = (__bf16*)a.out + (size_t)b * 196 * a.Cout + n0;
+        // 16-byte chunk c of row r sits at slot c ^ (r & (chunks per row - 1)).
+        constexpr int NCHK = 64 / EPC;  // 16-byte chunks per 64-channel row: 8 (bf16) / 16 (fp32)
+        T* const stage = sBrick + wave * 32 * 64;  // 4 / 8 KB per wave
+        T* const out = (T*)a.out + (size_t)b * 196 * a.Cout + n0;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             if (i >= nrb) continue;  // (wave-uniform)
@@ -1655,30 +1681,35 @@ __device__ __forceinline__ void conv3x3_img14_body(const ConvArgsBf& a)
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int n = 32 * j + 8 * g4 + 4 * hh;
                     const float4 bs = *(const float4*)(a.bias + n0 + n);
-                    bf16x4 v;
-                    v.x = (__bf16)fmaxf(acc[i][j][4 * g4 + 0] + bs.x, 0.0f);
-                    v.y = (__bf16)fmaxf(acc[i][j][4 * g4 + 1] + bs.y, 0.0f);
-                    v.z = (__bf16)fmaxf(acc[i][j][4 * g4 + 2] + bs.z, 0.0f);
-                    v.w = (__bf16)fmaxf(acc[i][j][4 * g4 + 3] + bs.w, 0.0f);
-                    *(bf16x4*)(stage + r31 * 64 + (((n >> 3) ^ (r31 & 7)) << 3) + (n & 4)) = v;
+                    const float v0 = fmaxf(acc[i][j][4 * g4 + 0] + bs.x, 0.0f), v1 = fmaxf(acc[i][j][4 * g4 + 1] + bs.y, 0.0f);
+                    const float v2 = fmaxf(acc[i][j][4 * g4 + 2] + bs.z, 0.0f), v3 = fmaxf(acc[i][j][4 * g4 + 3] + bs.w, 0.0f);
+                    T* const dst = stage + r31 * 64 + (((n / EPC) ^ (r31 & (NCHK - 1))) * EPC) + (n % EPC);
+                    if constexpr (F32) {
+                        *(float4*)dst = make_float4(v0, v1, v2, v3);
+                    } else {
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        bf16x4 v;
+                        v.x = (__bf16)v0, v.y = (__bf16)v1, v.z = (__bf16)v2, v.w = (__bf16)v3;
+                        *(bf16x4*)dst = v;
+                    }
                 }
             __builtin_amdgcn_wave_barrier();  // (wave-private tile: the wave's LDS writes are ordered before its reads)
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {  // 32 rows x 8 chunks of 16 bytes = 256 lane-stores
-                const int ch = it * 64 + lane, r = ch >> 3, c8 = ch & 7, qx = r >> 2;
-                const uint4 v = *(const uint4*)(stage + r * 64 + ((c8 ^ (r & 7)) << 3));
+            for (int it = 0; it < 32 * NCHK / 64; ++it) {  // 32 rows x NCHK chunks of 16 bytes
+                const int ch = it * 64 + lane, r = ch / NCHK, c8 = ch % NCHK, qx = r >> 2;
+                const uint4 v = *(const uint4*)(stage + r * 64 + ((c8 ^ (r & (NCHK - 1))) * EPC));
                 const int y = 2 * qy + ((r >> 1) & 1), x = 2 * qx + (r & 1);
-                if (qx < 7) *(uint4*)(out + (size_t)(y * 14 + x) * a.Cout + 8 * c8) = v;
+                if (qx < 7) *(uint4*)(out + (size_t)(y * 14 + x) * a.Cout + EPC * c8) = v;
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
 }
 
-template <bool POOLF32>
-__global__ void __launch_bounds__(512) k_conv3x3_img14_bf16(ConvArgsBf a)
+template <typename T, bool POOL>
+__global__ void __launch_bounds__(512) k_conv3x3_img14(Img14Args a)
 {
-    conv3x3_img14_body<POOLF32>(a);
+    conv3x3_img14_body<T, POOL>(a);
 }
 
 // ---------------------------------------------------------------- fp32 conv3x3, LDS-DMA staging ---------
@@ -2033,8 +2064,11 @@ constexpr long VA_RING_MAXGRID_F32 = 1024;  // fp32: the same threshold (0 and 4
 #ifndef VA_WS_DEFAULT
 #define VA_WS_DEFAULT 1     // bf16: the weights-resident kernel on the layers with 64 input channels
 #endif
+#ifndef VA_IMG14_F32_DEFAULT
+#define VA_IMG14_F32_DEFAULT 1  // fp32: the same kernel (T = float) on the 14 x 14 layers of the inference path
+#endif
 #ifndef VA_IMG14_DEFAULT
-#define VA_IMG14_DEFAULT 1  // bf16: the one-image-per-workgroup kernel on the 14 x 14 layers (k_conv3x3_img14_bf16)
+#define VA_IMG14_DEFAULT 1  // bf16: the one-image-per-workgroup kernel on the 14 x 14 layers (k_conv3x3_img14)
 #endif
 #ifndef VA_BPP_DEFAULT
 #define VA_BPP_DEFAULT 0    // bf16: 1 = the two-group halo-brick kernel wherever it applies (set after measurement)
@@ -2084,6 +2118,16 @@ int launch_conv_ex(int hw, int cin_pad, int cout, const float* wp, const float* 
     a.tiles_x = va_cdiv(hw, 1 << a.lgTW);
     a.tiles_y = va_cdiv(hw, 1 << a.lgTH);
     const int tiles_b = va_cdiv(B, a.TB);
+    // 14 x 14 layers (conv5_x) of the inference path: one image x 64 output channels per workgroup (k_conv3x3_img14<float>,
+    // round 3): 256 workgroups at batch 32 = one round of the CUs instead of 392 tap-major tiles (53 % MFMA utilisation)
+    if (f32_conv == 1 && VA_IMG14_F32_DEFAULT && hw == 14 && mask == nullptr && !linear && cin_pad % 32 == 0 && cout % 64 == 0) {
+        const Img14Args ia{in, wp, bias, out, B, cin_pad, cout};
+        const unsigned gridi = (unsigned)(B * (cout / 64));
+        if (pool) k_conv3x3_img14<float, true><<<gridi, 512, 0, st>>>(ia);
+        else k_conv3x3_img14<float, false><<<gridi, 512, 0, st>>>(ia);
+        VA_LAUNCH_CHECK();
+        return VA_OK;
+    }
     if (f32_conv == 1 && zeros != nullptr && cin_pad % kDmaBK == 0) {
         const long grid64 = (long)(cout / 64) * a.tiles_x * a.tiles_y * tiles_b;
         const int ksteps = 9 * (cin_pad / kDmaBK);
@@ -2184,12 +2228,13 @@ int launch_conv_bf16(const ConvLayer& L, const __bf16* zeros, int variant, const
         return VA_OK;
     }
     // 14 x 14 layers (conv5_x): one image x 64 output channels per workgroup, the image's halo brick staged once per
-    // 64-channel chunk (k_conv3x3_img14_bf16): the default there; variants 1, 2 keep the tap-major kernels for A/B and tests
+    // 64-channel chunk (k_conv3x3_img14): the default there; variants 1, 2 keep the tap-major kernels for A/B and tests
     if ((variant == 0 || variant >= 5) && VA_IMG14_DEFAULT && !L.xcol && L.hw == 14 && a.Cin % 64 == 0 && L.cout % 64 == 0 &&
         (long)B * (L.cout / 64) <= 65535L * 16 && ((out_f32 && L.pool) || (!out_f32 && !L.pool))) {
         const unsigned gridi = (unsigned)(B * (L.cout / 64));
-        if (out_f32) k_conv3x3_img14_bf16<true><<<gridi, 512, 0, st>>>(a);
-        else k_conv3x3_img14_bf16<false><<<gridi, 512, 0, st>>>(a);
+        const Img14Args ia{a.in, a.wp, a.bias, a.out, B, a.Cin, a.Cout};
+        if (out_f32) k_conv3x3_img14<__bf16, true><<<gridi, 512, 0, st>>>(ia);
+        else k_conv3x3_img14<__bf16, false><<<gridi, 512, 0, st>>>(ia);
         VA_LAUNCH_CHECK();
         return VA_OK;
     }
