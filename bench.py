@@ -169,11 +169,12 @@ def cpu_baseline(n_pairs_per_core, tv_kw, repeats=3):
                        "value = 1 / (10 / pairs_per_s + 1 / cnn_clips_per_s)" % (n_pairs, n_pairs_per_core, repeats, cores, repeats))
 
 
-def cnn_leg(pipe, rgb, stack, dtype, reps=5):
-    """Both VGG-16 streams of 32 clips on a precomputed flow volume, `reps` batches after one warm-up: TFLOP/s of the whole
-    leg (layout, classifier and launch gaps included) against the dense MFMA peak of the dtype."""
+def cnn_leg(pipe, rgb, stack, dtype, reps=10, warm=3):
+    """Both VGG-16 streams of 32 clips on a precomputed flow volume, `reps` batches after `warm` warm-up batches: TFLOP/s of the
+    whole leg (layout, classifier and launch gaps included) against the dense MFMA peak of the dtype."""
     import torch
-    pipe.run_batch(rgb, flow_stack=stack)
+    for _ in range(warm):
+        pipe.run_batch(rgb, flow_stack=stack)
     torch.cuda.synchronize()
     tc = time.perf_counter()
     for _ in range(reps):
