@@ -337,3 +337,40 @@ def test_bad_shapes_raise_value_error(weights3):
     with pytest.raises(ValueError):
         m.forward(torch.zeros(1, 3, 224, 224, dtype=torch.uint8, device="cuda"))  # no mean/std given
     m.close()
+
+
+@pytest.mark.parametrize("c_in,seed", [(3, 1), (20, 2)])
+def test_fp32_stream_against_an_independent_gpu_implementation(c_in, seed):
+    """A second, independent fp32 evaluation of the same network ON THE GPU -- torch's own ``conv2d`` / ``max_pool2d`` /
+    ``linear`` (MIOpen / rocBLAS kernels: nothing of this library) -- as a witness beside the torch-CPU oracle: the HIP
+    stream, the CPU oracle and the vendor kernels agree within the 1e-3 of the north star on every class score of a
+    9-clip batch (checker only: SURVEY.md section 7 allows MIOpen as an optional cross-check in tests, never on the
+    measured path)."""
+    import torch.nn.functional as F
+    from oracle import vgg_oracle
+    from video_analytics_amd import synth, vgg
+    w = synth.synth_vgg16_weights(c_in=c_in, seed=seed)
+    if c_in != 3:
+        w["conv_w"][0] = vgg_oracle.copy_first_layer(w["conv_w"][0], c_in)
+    x = _inputs(9, c_in, seed=40 + c_in)
+    m = vgg.Vgg16Stream(w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"], 101, 256)
+    feat, desc, logits = m.forward(x.cuda(), want_feat=True)
+    with torch.no_grad():
+        op, i = x.cuda(), 0
+        for v in vgg_oracle.VGG16_CFG:
+            if v == "M":
+                op = F.max_pool2d(op, 2, 2)
+            else:
+                op = F.relu(F.conv2d(op, w["conv_w"][i].cuda(), w["conv_b"][i].cuda(), padding=1))
+                i += 1
+        feat_g = op
+        op = op.reshape(op.size(0), -1)
+        for k in range(3):
+            op = F.relu(F.linear(op, w["fc_w"][k].cuda(), w["fc_b"][k].cuda()))
+        desc_g, logits_g = op, F.linear(op, w["fc_w"][3].cuda(), w["fc_b"][3].cuda())
+    _, desc_r, log_r = vgg_oracle.forward(x, w["conv_w"], w["conv_b"], w["fc_w"], w["fc_b"])
+    assert float((logits - logits_g).abs().max()) < TOL and float((desc - desc_g).abs().max()) < TOL
+    assert float((feat - feat_g).abs().max()) < TOL * max(1.0, float(feat_g.abs().max()))
+    assert float((logits_g.cpu() - log_r).abs().max()) < TOL  # (and the two witnesses agree with each other)
+    assert float(log_r.abs().max()) > 1.0
+    m.close()
