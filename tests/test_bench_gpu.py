@@ -27,7 +27,7 @@ def _json_line(stdout):
 
 def test_bench_started_bare_runs_two_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--cpu-clips", "0"], capture_output=True, text=True, timeout=900,
+                        "--cpu-clips", "0", "--main-only"], capture_output=True, text=True, timeout=900,
                        env=_env(VA_DIST_BACKEND="gloo", VA_FORCE_DEVICE="0"))
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
