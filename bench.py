@@ -57,6 +57,7 @@ CLOCK_GHZ_MAX = 2.4
 GFLOP_PER_CLIP = 62.852   # two VGG-16 streams, SURVEY.md section 2a / 8d
 BATCH = 32
 TVL1_SRC = os.path.join(ROOT, "video_analytics_amd", "csrc", "tvl1.hip")
+VGG_SRC = os.path.join(ROOT, "video_analytics_amd", "csrc", "vgg.hip")
 
 
 def git_blob_hash(path):
@@ -77,6 +78,20 @@ def committed_profile(name):
         if d.get("tvl1_hip_blob") == git_blob_hash(TVL1_SRC):
             d["_path"] = os.path.relpath(path, ROOT)
             return d
+    return None
+
+
+def committed_mfma_util(dtype):
+    """Counter-based MFMA utilisation of the conv launches (profiles/rNN/conv_mfma_util.json, tools/profile_cnn.sh) of the
+    latest round whose stamp equals the current vgg.hip; None otherwise."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "conv_mfma_util.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("vgg_hip_blob") == git_blob_hash(VGG_SRC) and dtype in d:
+            return dict(mfma_util=d[dtype]["mfma_util"], source=os.path.relpath(path, ROOT))
     return None
 
 
@@ -174,8 +189,9 @@ def cnn_leg(pipe, rgb, stack, dtype, reps=10, warm=3):
     whole leg (layout, classifier and launch gaps included) against the dense MFMA peak of the dtype."""
     import torch
     for _ in range(warm):
-        pipe.run_batch(rgb, flow_stack=stack)
+        out = pipe.run_batch(rgb, flow_stack=stack)
     torch.cuda.synchronize()
+    logits = torch.stack([out["logits_s"], out["logits_t"]], 1).clone()
     tc = time.perf_counter()
     for _ in range(reps):
         pipe.submit(rgb, flow_stack=stack)
@@ -184,9 +200,12 @@ def cnn_leg(pipe, rgb, stack, dtype, reps=10, warm=3):
     ms = (time.perf_counter() - tc) / reps * 1e3
     tf = BATCH * GFLOP_PER_CLIP / ms  # GFLOP / ms = TFLOP/s
     peak = MFMA_PEAK_TFLOPS[dtype]
+    util = committed_mfma_util(dtype)
     return dict(bound="mfma", kernel="k_conv3x3_* + k_fc_* (both VGG-16 streams, 32 clips)", achieved=tf, peak=peak,
                 unit="TFLOP/s", frac=tf / peak, ms_per_batch=ms, gflop_per_clip=GFLOP_PER_CLIP, dtype=dtype,
-                note="whole CNN leg incl. layout, FC and launch gaps; counter-based MFMA utilisation per layer: profiles/")
+                mfma_util_counters=util["mfma_util"] if util else None, mfma_util_source=util["source"] if util else None,
+                note="whole CNN leg incl. layout, FC and launch gaps; mfma_util_counters: conv launches only, from the "
+                     "committed counter pass on this vgg.hip (per layer: profiles/rNN/conv_mfma_util.txt)"), logits
 
 
 def tvl1_hd_leg(args, dev, n_pairs=16, reps=2):
@@ -373,13 +392,17 @@ def main():
             # (a synthetic flow volume: the CNN's time does not depend on the values, and no TV-L1 work is added to the run)
             st2 = stack if stack is not None else torch.from_numpy(
                 synth.hash_uniform(5, 5, BATCH * 20 * 224 * 224).reshape(BATCH, 20, 224, 224) * 4.0 - 2.0).to(dev)
-            cnn = cnn_leg(pipe, rgb, st2, args.cnn_dtype)
+            cnn, lg1 = cnn_leg(pipe, rgb, st2, args.cnn_dtype)
             pipe.close()
             other = "bf16" if args.cnn_dtype == "f32" else "f32"
             pipe2 = pipeline.TwoStreamPipeline(device=local_rank, tvl1_params=params, flow_streams=args.flow_streams, cnn_dtype=other)
-            leg2 = cnn_leg(pipe2, rgb, st2, other)
+            leg2, lg2 = cnn_leg(pipe2, rgb, st2, other)
             pipe2.close()
             cnn, cnn_bf16 = (cnn, leg2) if args.cnn_dtype == "f32" else (leg2, cnn)
+            # BASELINE config 5 asks for the deviation of the bf16 class scores from the fp32 ones: same weights, same inputs
+            cnn_bf16["max_abs_dlogit_vs_f32"] = float((lg1 - lg2).abs().max().item())
+            cnn_bf16["logit_range_f32"] = float((lg1 if args.cnn_dtype == "f32" else lg2).abs().max().item())
+            cnn_bf16["argmax_agreement"] = float((lg1.argmax(-1) == lg2.argmax(-1)).float().mean().item())
         cpu = None
         if world == 1 and args.cpu_pairs_per_core > 0 and not args.main_only:
             cpu = cpu_baseline(args.cpu_pairs_per_core, tv_kw)

@@ -60,6 +60,10 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     assert hd["pairs_per_s"] > 10 and 0.0 < hd["frac"] <= 1.0 and hd["finite"]
     for key, dt in (("roofline_cnn", "f32"), ("roofline_cnn_bf16", "bf16")):
         assert d[key]["dtype"] == dt and d[key]["bound"] == "mfma" and 0.0 < d[key]["frac"] <= 1.0
+        assert "mfma_util_counters" in d[key]  # from the committed counter pass when it was taken on this vgg.hip, else null
+    # config 5: the deviation of the bf16 class scores from the fp32 ones on the same weights and inputs, measured in the run
+    b = d["roofline_cnn_bf16"]
+    assert 0.0 < b["max_abs_dlogit_vs_f32"] < 3e-2 * max(1.0, b["logit_range_f32"]) and b["argmax_agreement"] >= 0.9
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32"
 
 

@@ -45,7 +45,24 @@ def main(pmc_dir, trace_dir):
         print("%-56s %6d %9.1f %8.1f%% %8.2f %8.1f" % (k, c, us, 100 * busy / (cyc * 1024), cyc / (us * 1e3) if us else 0,
                                                        mops / (us * 1e-6) / 1e12 if us else 0))
     print("all conv launches: MFMA utilisation %.1f %%" % (100 * tot_busy / tot_cyc))
+    return tot_busy / tot_cyc
+
+
+def add_to_summary(path, dtype, util):
+    """profiles/rNN/conv_mfma_util.json: the per-dtype figure bench.py attaches to roofline_cnn*, stamped with vgg.hip's blob."""
+    import json
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import VGG_SRC, git_blob_hash
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    d["vgg_hip_blob"] = git_blob_hash(VGG_SRC)
+    d["workload"] = "tools/bench_cnn_only.py, the two models one after the other (ONE_STREAM=1), 32 clips"
+    d["counters"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), all conv launches"
+    d[dtype] = {"mfma_util": util}
+    json.dump(d, open(path, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    u = main(sys.argv[1], sys.argv[2])
+    if len(sys.argv) > 4:  # ... <summary.json> <dtype>
+        add_to_summary(sys.argv[3], sys.argv[4], u)

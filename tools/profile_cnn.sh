@@ -2,6 +2,7 @@
 # MFMA utilisation of the conv kernels (profiles/rNN/conv_mfma_util.txt): counter pass + kernel trace of the CNN-only
 # workload, fp32 and bf16.   bash tools/profile_cnn.sh gpurun_out/r02m
 set -e
+rm -f $1/conv_mfma_util.txt $1/conv_mfma_util.json
 export ONE_STREAM=1  # the two models one after the other: per-kernel durations are their own
 P=$1
 mkdir -p $P
@@ -12,7 +13,7 @@ for dt in f32 bf16; do
   python3 tools/bench_cnn_only.py $dt > $P/plain_$dt.log 2>&1
   echo "== $dt ==" >> $P/conv_mfma_util.txt
   tail -1 $P/plain_$dt.log >> $P/conv_mfma_util.txt
-  python3 tools/mfma_util.py $P/pmc_$dt $P/trace_$dt >> $P/conv_mfma_util.txt
+  python3 tools/mfma_util.py $P/pmc_$dt $P/trace_$dt $P/conv_mfma_util.json $dt >> $P/conv_mfma_util.txt
 done
 find $P -name "*_agent_info.csv" -delete
 cat $P/conv_mfma_util.txt
