@@ -23,7 +23,9 @@ Prints one JSON line (rank 0).
                 counters of the committed profile of this very tvl1.hip and bench configuration, or null),
                 `algorithmic_64B_x_hbm_peak` (SURVEY.md section 8d's 64 B per pixel-iteration over the HBM peak: > 1 because
                 the kernels fuse 10-16 iterations in registers -- a byte model they do not execute, not an efficiency) and
-                `ns_per_kpx_iter_l0..4` (per pyramid level, live).
+                `ns_per_kpx_iter_l0..4` (per pyramid level, live, inside the step: the coarsest level shares the GPU with the spatial
+                CNN) and `ns_per_kpx_iter_tvl1_only_l0..4` / `tvl1_only_ms_per_batch` (the same batch's TV-L1 alone, after the
+                timed region).
   tvl1_hd       BASELINE config 3 after the timed region: TV-L1 only, 16 pairs 1280x720, 5 x 5 x 300, pairs/s and its fraction.
   roofline_cnn / roofline_cnn_bf16   the conv/FC stack alone (fp32 parity configuration / BASELINE config 5's bf16 per GPU):
                 TFLOP/s of a CNN-only leg timed after the main region, against the dense MFMA peak of the dtype.
@@ -208,6 +210,33 @@ def cnn_leg(pipe, rgb, stack, dtype, reps=10, warm=3):
                      "committed counter pass on this vgg.hip (per layer: profiles/rNN/conv_mfma_util.txt)"), logits
 
 
+def tvl1_only_leg(pipe, gray, params, n_streams, device, reps=2):
+    """The benchmark batch's TV-L1 (320 pairs, same streams, same parameters) with nothing else on the GPU, after the timed
+    region: ms per batch and the per-level cost in the units of `ns_per_kpx_iter_l*` (summed over the streams' calls)."""
+    import torch
+    from video_analytics_amd import flow as vflow
+    vflow.tvl1_flow_concurrent(gray, params, n_streams)
+    torch.cuda.synchronize()
+    vflow.profile_enable(True, device)
+    vflow.profile_read(reset=True, device=device)
+    vflow.profile_levels(16, reset=True, device=device)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        vflow.tvl1_flow_concurrent(gray, params, n_streams)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    p = vflow.profile_read(reset=False, device=device)
+    levels = vflow.profile_levels(16, reset=True, device=device)
+    vflow.profile_read(reset=True, device=device)
+    vflow.profile_enable(False, device)
+    out = {"tvl1_only_ms_per_batch": ms,
+           "tvl1_only_kernel_ms_per_batch": (p["union_ms"] if p["union_ms"] > 0 else p["ms"]) / reps}
+    for s, l in enumerate(levels):
+        if l["px_iters"]:
+            out["ns_per_kpx_iter_tvl1_only_l%d" % s] = (l["ms"] * 1e6) / (l["px_iters"] / 1e3)
+    return out
+
+
 def tvl1_hd_leg(args, dev, n_pairs=16, reps=2):
     """BASELINE config 3: TV-L1 only on 1280x720 pairs (same texture / warp generator, seed 3; 16 pairs resident; fixed
     5 x 5 x 300 schedule), timed after the main region.  pairs/s, and the same fp32-vector fraction as `roofline`."""
@@ -386,6 +415,10 @@ def main():
             for l in per_level:
                 roof["ns_per_kpx_iter_l%d" % l["level"]] = l["ns_per_kpx_iter"]
         hd = cnn = cnn_bf16 = None
+        if world == 1 and not args.main_only and roof is not None and stack is None:
+            # the per-level figures above are taken INSIDE the two-stream step, where the spatial CNN runs beside the coarsest
+            # level; the same batch's TV-L1 alone (no CNN on the GPU) separates the kernels' own cost from that sharing
+            roof.update(tvl1_only_leg(pipe, gray, params, args.flow_streams, local_rank))
         if world == 1 and not args.main_only:
             hd = tvl1_hd_leg(args, dev)
             # CNN-only legs (outside the timed region): both VGG-16 streams on precomputed flow volumes

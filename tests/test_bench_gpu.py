@@ -55,6 +55,10 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     assert abs(roof["achieved"] - 55.0 * roof["px_iters_per_step"] / (roof["kernel_ms_per_step"] * 1e-3) / 1e12) < 1e-6 * roof["achieved"]
     assert abs(roof["px_iters_per_step"] - 320 * 1500 * sum(n * n for n in (224, 179, 143, 114, 91))) < 1.0
     assert 0.0 < roof["frac_valu_needed"] <= 1.0
+    # the same batch's TV-L1 with no CNN beside it: the levels' own cost (the coarsest level shares the GPU with the spatial CNN
+    # inside a step)
+    assert 0.0 < roof["ns_per_kpx_iter_tvl1_only_l4"] <= roof["ns_per_kpx_iter_l4"] * 1.05
+    assert 0.0 < roof["tvl1_only_kernel_ms_per_batch"] <= roof["tvl1_only_ms_per_batch"] < d["ms_per_step"]
     # BASELINE configs 3 and 5 in the same line: TV-L1 only at 1280x720, the bf16 conv stack per GPU
     hd = d["tvl1_hd"]
     assert hd["pairs_per_s"] > 10 and 0.0 < hd["frac"] <= 1.0 and hd["finite"]
