@@ -259,11 +259,12 @@ struct WgradArgs {
 // pixel-major ([k][m], [k][n], row stride = width + 32 floats: the two k rows of an MFMA fragment read fall in
 // different bank halves), operands one float per lane for v_mfma_f32_32x32x2_f32.
 template <int WM, int WN>
-__global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs a)
+__global__ void __launch_bounds__(WM * WN * 64) k_conv_wgrad(WgradArgs a)
 {
-    constexpr int BK = 16, BM = WM * 64, BN = WN * 64, LSA = BM + 32, LSB = BN + 32;
-    constexpr int RA = 256 / (BM / 4), RB = 256 / (BN / 4);  // pixel rows one pass of the 256 loader threads covers
-    constexpr int A_PER = BK / RA, B_PER = BK / RB;          // float4 loads per thread and step
+    constexpr int BK = 16, BM = WM * 64, BN = WN * 64, LSA = BM + 32, LSB = BN + 32, NT = WM * WN * 64;
+    static_assert(NT % (BM / 4) == 0 && NT % (BN / 4) == 0, "a loader thread keeps one float4 column over its passes");
+    constexpr int RA = NT / (BM / 4), RB = NT / (BN / 4);        // pixel rows one pass of the loader threads covers
+    constexpr int A_PER = (BK + RA - 1) / RA, B_PER = (BK + RB - 1) / RB;  // float4 loads per thread and step (the last pass may be partial)
     __shared__ __attribute__((aligned(16))) float sA[2][BK * LSA], sB[2][BK * LSB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -295,12 +296,14 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs a)
         for (int i = 0; i < A_PER; ++i) {
             const long p = pbase + krowa + RA * i;
             ra[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (BK % RA != 0 && krowa + RA * i >= BK) continue;
             if (p < p1 && mok) ra[i] = *reinterpret_cast<const f32x4*>(a.dy + p * Cout + m0 + ca4);
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const long p = pbase + krowb + RB * i;
             rb[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (BK % RB != 0 && krowb + RB * i >= BK) continue;
             if (p < p1 && nok) {
                 const int x = (int)(p % H);
                 const long r = p / H;
@@ -312,9 +315,11 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs a)
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) *reinterpret_cast<f32x4*>(&sA[buf][(krowa + RA * i) * LSA + ca4]) = ra[i];
+        for (int i = 0; i < A_PER; ++i)
+            if (BK % RA == 0 || krowa + RA * i < BK) *reinterpret_cast<f32x4*>(&sA[buf][(krowa + RA * i) * LSA + ca4]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) *reinterpret_cast<f32x4*>(&sB[buf][(krowb + RB * i) * LSB + cb4]) = rb[i];
+        for (int i = 0; i < B_PER; ++i)
+            if (BK % RB == 0 || krowb + RB * i < BK) *reinterpret_cast<f32x4*>(&sB[buf][(krowb + RB * i) * LSB + cb4]) = rb[i];
     };
 
     const int r31 = lane & 31, hh = lane >> 5;
@@ -508,8 +513,8 @@ WgradPlan plan_wgrad(int B, int hw, int cout, int cin_pad)
 {
     WgradPlan p;
     const int N = 9 * cin_pad;
-    p.BM = cout <= 64 ? 64 : 128;  // 64 x 256 tiles for the 64-channel layers, 128 x 128 otherwise
-    p.BN = cout <= 64 ? 256 : 128;
+    p.BM = cout <= 64 ? 64 : 128;  // 64 x 192 tiles (three waves) for the 64-channel layers, 128 x 128 otherwise:
+    p.BN = cout <= 64 ? 192 : 128;  // conv1_2's 576 columns are three tiles (256-column tiles: 2.25), the first layer's 144 one
     p.Mpad = va_cdiv(cout, p.BM) * p.BM;
     p.Npad = va_cdiv(N, p.BN) * p.BN;
     const long P = (long)B * hw * hw;
@@ -739,7 +744,7 @@ extern "C" int va_vgg16_train_step(va_vgg16* m, const void* x, int x_is_u8, cons
         a.Mpad = wp.Mpad;
         a.P = (long)B * L.hw * L.hw;
         a.chunk = wp.chunk;
-        if (wp.BM == 64) k_conv_wgrad<1, 4><<<dim3(wp.Npad / 256, wp.Mpad / 64, wp.S), 256, 0, st>>>(a);
+        if (wp.BM == 64) k_conv_wgrad<1, 3><<<dim3(wp.Npad / 192, wp.Mpad / 64, wp.S), 192, 0, st>>>(a);
         else k_conv_wgrad<2, 2><<<dim3(wp.Npad / 128, wp.Mpad / 128, wp.S), 256, 0, st>>>(a);
         const size_t nw = (size_t)L.cout * a.N;
         k_wgrad_reduce_sgd<<<(unsigned)((nw + 31) / 32), 256, 0, st>>>(slab, L.wp, L.mom_w, L.cout, a.N, wp.Mpad, wp.Npad, wp.S, lr, momentum);
