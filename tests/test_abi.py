@@ -70,9 +70,13 @@ def test_tile_plan_of_the_benchmark_pyramid():
     224x224 benchmark pyramid in fixed-iteration mode, and the epsilon mode's forced block depth 1."""
     from video_analytics_amd import _ffi, flow
     plan = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0))
-    # the 224^2, 179^2 (two 128-column strips each) and 114^2 (one strip) levels stream (two waves, 16 iterations per pass);
+    # the 224^2, 179^2 (two 128-column strips each) and 114^2 (one strip) levels stream through FOUR waves (round 3): 4 x 4
+    # levels = 16 iterations per pass, 4 x 5 = 20 on 179^2, where a 20-column halo still costs no third strip;
     # 143^2 (strips 56 % full) and 91^2 (too few jobs) iterate on 64x64 register tiles -- the measured choice
     assert [(d["tile_w"], d["tile_h"], d["waves"], d["block_iters"], d["tiles_x"]) for d in plan] == [
+        (128, 0, 4, 16, 2), (128, 0, 4, 20, 2), (64, 64, 4, 12, 3), (128, 0, 4, 16, 1), (64, 64, 4, 16, 2)]
+    two = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, stream_waves=2))  # the two-wave form of rounds 1-2
+    assert [(d["tile_w"], d["tile_h"], d["waves"], d["block_iters"], d["tiles_x"]) for d in two] == [
         (128, 0, 2, 16, 2), (128, 0, 2, 16, 2), (64, 64, 4, 12, 3), (128, 0, 2, 16, 1), (64, 64, 4, 16, 2)]
     if _ffi.has_experiments():  # `make EXPERIMENTS=1`: the measured-slower kernel families are compiled in
         rows = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 9))  # k_iter_rows: 4, 3, 3, 2, 2 px per lane
@@ -81,7 +85,7 @@ def test_tile_plan_of_the_benchmark_pyramid():
         ppl3 = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 8, stream_ppl=3))
         assert [(d["tile_w"], d["block_iters"], d["tiles_x"]) for d in ppl3] == [(192, 10, 2), (192, 10, 1), (192, 10, 1), (192, 10, 1), (192, 10, 1)]
     else:  # a default build refuses the experiment switches loudly instead of silently running something else
-        for kw in (dict(tile_mask=1 << 9), dict(stream_ppl=3), dict(stream_waves=3), dict(stream_waves=4), dict(stream_waves=5), dict(stream_waves=6), dict(stream_queue=1),
+        for kw in (dict(tile_mask=1 << 9), dict(stream_ppl=3), dict(stream_waves=3), dict(stream_waves=4), dict(stream_waves=5), dict(stream_waves=6), dict(stream_waves=9), dict(stream_waves=12), dict(stream_queue=1),
                    dict(rows_levels=1), dict(rows_cfg=40)):
             assert _ffi.lib().va_tvl1_workspace_bytes(224, 224, 1, 2, _ffi.default_tvl1_params(epsilon=0.0, **kw)) == 0, kw
             assert b"VA_EXPERIMENTS" in _ffi.lib().va_last_error()

@@ -90,6 +90,24 @@ def test_streaming_kernel_bit_exact(oracle_tvl1, H, W, nch):
         assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("waves", [0, 2, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("H,W,nch", [(224, 224, 0), (224, 224, 2), (179, 179, 0), (143, 143, 1), (114, 114, 2), (100, 64, 3), (129, 225, 2),
+                                     (57, 131, 1), (33, 130, 1), (17, 19, 0), (150, 300, 2)])
+def test_streaming_kernel_three_and_four_wave_forms_bit_exact(oracle_tvl1, waves, H, W, nch):
+    if waves >= 9:
+        _needs_experiments()
+    # stream_waves = 0: the default choice (four waves x 4 levels, x 5 where a 20-column halo costs no third strip), 2: the
+    # two-wave form, 7 / 8: 4 x 4 / 4 x 5 wherever they fit, 9 ... 12 (experiments): 3 x 5, 3 x 6, 4 x 6, 4 x 3.  The passes of
+    # a warp step share the iterations evenly (44 = 15 + 15 + 14, 57 = 19 + 19 + 19, 29 = 15 + 14): every pass must end in the
+    # last wave, otherwise the step falls back to the two-wave form (10, 23); 300 columns: three strips, where only the
+    # one-wave form runs; chunks of rows; the smallest frames
+    gray = _frames(2, 2, H, W, seed=3 * H + W)
+    for iters, warps, nscales in ((16, 1, 1), (44, 2, 3), (29, 1, 2), (57, 1, 1), (40, 1, 2), (23, 1, 1)):
+        ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=warps, nscales=nscales, tile_mask=1 << 8,
+                             stream_chunks=nch, stream_waves=waves)
+        assert np.array_equal(out, ref), "max abs diff %g (iters %d)" % (np.abs(out - ref).max(), iters)
+
+
 @pytest.mark.parametrize("ppl", [2, 3])
 @pytest.mark.parametrize("H,W,nch", [(179, 179, 0), (143, 143, 2), (100, 64, 3), (64, 300, 1), (150, 400, 3), (57, 131, 1), (33, 190, 1),
                                      (129, 225, 2), (40, 700, 1), (16, 16, 0)])

@@ -976,11 +976,11 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
 #pragma clang loop unroll(full)
         for (int f = 0; f < kNF_RO; ++f) ring_put(r, f, zero);
     if constexpr (NWV > 1) {
-        if (wv == 0)
+        if (wv < NWV - 1)  // wave w zeroes the hand-over rows it will write
 #pragma clang loop unroll(full)
             for (int f = 0; f < kNF_STATE; ++f) {
-                if_put(0, 0, f, zero);
-                if_put(0, 1, f, zero);
+                if_put(wv, 0, f, zero);
+                if_put(wv, 1, f, zero);
             }
         __syncthreads();
     }
@@ -1236,16 +1236,26 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
     };
     if constexpr (NWV == 1) {
         run(std::integral_constant<int, 0>{});
-    } else {
+    } else if constexpr (NWV == 2) {
         if (wv == 0) run(std::integral_constant<int, 0>{});
         else run(std::integral_constant<int, NWV - 1>{});
+    } else if constexpr (NWV == 3) {
+        if (wv == 0) run(std::integral_constant<int, 0>{});
+        else if (wv == 1) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 2>{});
+    } else {
+        static_assert(NWV == 4, "pipelines of one to four waves");
+        if (wv == 0) run(std::integral_constant<int, 0>{});
+        else if (wv == 1) run(std::integral_constant<int, 1>{});
+        else if (wv == 2) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 3>{});
     }
 }
 
 // One launch = one pass (a.K iterations) of every pair of the call: the grid is (strips x chunks, pairs).
 template <int PPL, int KH, int NWV, bool FAST, int NCH = 1>
 __global__ void __launch_bounds__(NWV * 64)
-    __attribute__((amdgpu_waves_per_eu((NWV == 1 && KH > 10) ? 1 : 2, (NWV == 1 && KH > 10) ? 1 : 2)))
+    __attribute__((amdgpu_waves_per_eu((NWV == 1 && KH > 10) ? 1 : 2, (NWV == 1 && KH > 10) ? 1 : NWV >= 3 ? 4 : 2)))
     k_iter_stream(StreamArgs a)
 {
     unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
@@ -1383,7 +1393,12 @@ constexpr int kStreamBit = 1 << 8;  // va_tvl1_params.tile_mask bit: iterate wit
 struct StreamPick {
     int nsx, nch, R, HX, two, ppl, deep1;
     int chains;  // chains of levels per wave (stream_job, NCH): 1, or 2 with stream_waves = 5 (one deep wave) / 6 (two waves)
+    int mw_nwv, mw_kh;  // > 0: the pipeline of mw_nwv waves x mw_kh levels (3 or 4 waves; stream_waves >= 7)
 };
+// stream_waves >= 7: pipelines of three or four waves (waves x levels per wave)
+constexpr int kMwShapes[][2] = {{4, 4}, {4, 5}, {3, 5}, {3, 6}, {4, 6}, {4, 3}};
+constexpr int kNumMwShapes = (int)(sizeof(kMwShapes) / sizeof(kMwShapes[0]));
+constexpr int kMwFirst = 7;
 // Pixels per lane of k_iter_stream: 2 (128-column strips) unless va_tvl1_params.stream_ppl asks for 3 (192-column
 // strips: a 129..192-column level then is ONE strip without x halo -- 179^2 fills 93 % of the lanes instead of 70 % of
 // two 128-column strips).  Measured on the benchmark's 179^2 / 143^2 levels (320 pairs, two streams): 33.6 / 25.6 ms
@@ -1408,6 +1423,25 @@ void launch_stream(int ppl, dim3 grid, hipStream_t st, const StreamArgs& sa)
     (void)ppl;
     k_iter_stream<2, TWO ? stream_kh2(2) : stream_k1(2), NWV, FAST><<<grid, NWV * 64, 0, st>>>(sa);
 }
+template <int NWV, int KH>
+void launch_stream_mw1(bool fast, dim3 grid, hipStream_t st, const StreamArgs& sa)
+{
+    if (fast) k_iter_stream<2, KH, NWV, true><<<grid, NWV * 64, 0, st>>>(sa);
+    else k_iter_stream<2, KH, NWV, false><<<grid, NWV * 64, 0, st>>>(sa);
+}
+void launch_stream_mw(int nwv, int kh, bool fast, dim3 grid, hipStream_t st, const StreamArgs& sa)
+{
+    if (nwv == 4 && kh == 5) return launch_stream_mw1<4, 5>(fast, grid, st, sa);
+#ifdef VA_EXPERIMENTS
+    if (nwv == 3 && kh == 5) return launch_stream_mw1<3, 5>(fast, grid, st, sa);
+    if (nwv == 3 && kh == 6) return launch_stream_mw1<3, 6>(fast, grid, st, sa);
+    if (nwv == 4 && kh == 6) return launch_stream_mw1<4, 6>(fast, grid, st, sa);
+    if (nwv == 4 && kh == 3) return launch_stream_mw1<4, 3>(fast, grid, st, sa);
+#endif
+    (void)nwv;
+    (void)kh;
+    launch_stream_mw1<4, 4>(fast, grid, st, sa);
+}
 // Strips of a level.  Two-wave pipeline (16 iterations per pass) where the deeper x halo costs nothing, i.e. where the
 // level has no interior strip (w <= 224); wider levels use the one-wave pipeline (10 per pass, halo 10: measured on
 // the 1280x720 pyramid).  va_tvl1_params.stream_waves = 1 (experiment switch): one-wave everywhere.
@@ -1425,6 +1459,27 @@ void stream_strips(const va_tvl1_params* p, int w, StreamPick& sp)
     // on 179^2 against 41.6 / 32.9 for the two-wave form: more resident waves do not fill the idle issue slots.)
     sp.HX = va_cdiv(sp.two ? 2 * stream_kh2(sp.ppl) : stream_k1(sp.ppl), hq) * hq;
     sp.nsx = tiles_1d(w, SW, sp.HX);
+    // Pipelines of FOUR waves (round 3): 4 x 4 levels (16 iterations per pass, 143 registers: three waves per SIMD) or, where
+    // a 20-column halo still costs no third strip, 4 x 5 levels (20 per pass, 167 registers).  Measured per level on the
+    // benchmark's pyramid (320 pairs on two streams, ms per 5 x 300 iterations, against the two-wave form): 224^2 38.7 / 41.7
+    // (4 x 4, whole columns per job), 179^2 28.4 / 33.5 (4 x 5), 114^2 12.4 / 14.4 (4 x 4, two chunks): four shallow waves
+    // need a quarter of the strip x chunk jobs to fill the GPU, so that the levels are cut into fewer chunks of rows (each
+    // chunk costs its halo rows and the pipeline's fill), and leave room for a third wave per SIMD.
+    // stream_waves: 0 = this choice, 2 = the two-wave form, 1 = one wave everywhere, 7 = 4 x 4 everywhere it fits,
+    // (VA_EXPERIMENTS) 8 ... 12 = the other shapes of kMwShapes.
+    const int sw = p->tuning[VA_TUNE_STREAM_WAVES];
+    int shape = -1;
+    if (sw >= kMwFirst && sw < kMwFirst + kNumMwShapes) shape = sw - kMwFirst;
+    else if (sw == 0 && sp.two) shape = (w > SW && tiles_1d(w, SW, 20) <= 2) ? 1 : 0;
+    if (shape >= 0 && sp.two && sp.ppl == 2) {
+        const int nwv = kMwShapes[shape][0], kh = kMwShapes[shape][1], hx = va_cdiv(nwv * kh, 2) * 2;
+        if (tiles_1d(w, SW, hx) <= 2) {  // like the two-wave form: only where the deeper x halo costs no third strip
+            sp.mw_nwv = nwv;
+            sp.mw_kh = kh;
+            if (hx > sp.HX) sp.HX = hx;  // (a pass that falls back to the two-wave form runs with this halo too)
+            sp.nsx = tiles_1d(w, SW, sp.HX);
+        }
+    }
 }
 StreamPick pick_stream(const va_tvl1_params* p, int w, int h, int npairs)
 {
@@ -1433,7 +1488,7 @@ StreamPick pick_stream(const va_tvl1_params* p, int w, int h, int npairs)
     // chunks of rows: the number of jobs (strip x chunk x pair) that keeps the GPU busiest was measured with one and
     // with two concurrent calls on different HIP streams: ~1024 one-wave jobs, ~640 two-wave jobs per call (256 CUs x
     // 8 waves); rows per chunk not below 32
-    const int slots = p->tuning[VA_TUNE_STREAM_SLOTS] > 0 ? p->tuning[VA_TUNE_STREAM_SLOTS] : (sp.two ? 640 : 1024);
+    const int slots = p->tuning[VA_TUNE_STREAM_SLOTS] > 0 ? p->tuning[VA_TUNE_STREAM_SLOTS] : sp.mw_nwv ? 320 : (sp.two ? 640 : 1024);
     int nch = p->tuning[VA_TUNE_STREAM_CHUNKS];
     if (nch <= 0) nch = (int)((double)slots / ((double)npairs * sp.nsx) + 0.5);
     if (nch > h / 32) nch = h / 32;
@@ -1624,17 +1679,17 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
                  "va_tvl1: rows_levels must be -1 or a level bit set, rows_cfg in [0,255]");
     VA_CHECK_ARG(p->tuning[VA_TUNE_STREAM_PPL] == 0 || p->tuning[VA_TUNE_STREAM_PPL] == 2 || p->tuning[VA_TUNE_STREAM_PPL] == 3, "va_tvl1: stream_ppl must be 0 (default), 2 or 3");
     VA_CHECK_ARG(p->tuning[VA_TUNE_STREAM_QUEUE] >= 0 && p->tuning[VA_TUNE_STREAM_QUEUE] <= 2, "va_tvl1: stream_queue must be 0 (default), 1 (queued) or 2 (a launch per pass)");
-    VA_CHECK_ARG(p->tuning[VA_TUNE_STREAM_LEVELS] >= -1 && p->tuning[VA_TUNE_STREAM_LEVELS] < (1 << kMaxScales) && (p->tuning[VA_TUNE_STREAM_WAVES] == 0 || p->tuning[VA_TUNE_STREAM_WAVES] == 1 || (p->tuning[VA_TUNE_STREAM_WAVES] >= 3 && p->tuning[VA_TUNE_STREAM_WAVES] <= 6)) &&
+    VA_CHECK_ARG(p->tuning[VA_TUNE_STREAM_LEVELS] >= -1 && p->tuning[VA_TUNE_STREAM_LEVELS] < (1 << kMaxScales) && (p->tuning[VA_TUNE_STREAM_WAVES] >= 0 && p->tuning[VA_TUNE_STREAM_WAVES] < kMwFirst + kNumMwShapes) &&
                      p->tuning[VA_TUNE_STREAM_CHUNKS] >= 0 && p->tuning[VA_TUNE_STREAM_SLOTS] >= 0,
-                 "va_tvl1: stream_levels must be -1 or a level bit set, stream_waves one of 0, 1, 3, 4, 5, 6, stream_chunks and stream_slots >= 0");
+                 "va_tvl1: stream_levels must be -1 or a level bit set, stream_waves in [0, 12], stream_chunks and stream_slots >= 0");
     VA_CHECK_ARG(p->tau / p->theta <= 1000.0f && p->lambda * p->theta <= 1000.0f, "va_tvl1: tau/theta and lambda*theta must be <= 1000");
     VA_CHECK_ARG(!(p->tuning[VA_TUNE_STREAM_WAVES] == 3 && p->fast_math), "va_tvl1: stream_waves = 3 (one deep wave) is compiled for the exact arithmetic only");
     if (!kVaExperiments) {
         const int sw = p->tuning[VA_TUNE_STREAM_WAVES];
-        VA_CHECK_ARG(sw != 3 && sw != 4 && sw != 5 && sw != 6 && p->tuning[VA_TUNE_STREAM_PPL] != 3 && p->tuning[VA_TUNE_STREAM_QUEUE] != 1 &&
+        VA_CHECK_ARG(sw != 3 && sw != 4 && sw != 5 && sw != 6 && sw <= kMwFirst + 1 && p->tuning[VA_TUNE_STREAM_PPL] != 3 && p->tuning[VA_TUNE_STREAM_QUEUE] != 1 &&
                          p->tuning[VA_TUNE_ROWS_LEVELS] <= 0 && p->tuning[VA_TUNE_ROWS_CFG] == 0 && !(p->tile_mask & kRowsBit),
                      "va_tvl1: this tuning value selects an experiment kernel (k_iter_rows, k_iter_stream_q, k_iter_stream4, one deep "
-                     "wave, two chains per wave, 3 pixels per lane); build the library with -DVA_EXPERIMENTS (make EXPERIMENTS=1) to get them");
+                     "wave, two chains per wave, four waves x four levels, 3 pixels per lane); build the library with -DVA_EXPERIMENTS (make EXPERIMENTS=1) to get them");
     }
     return VA_OK;
 }
@@ -1766,7 +1821,8 @@ extern "C" int va_tvl1_tile_plan(int w, int h, const va_tvl1_params* p, int* out
         if (lk == LK_STREAM) {
             StreamPick sp{};
             stream_strips(p, ws[s], sp);
-            const int plan[6] = {64 * sp.ppl, 0, sp.two ? 2 : 1, sp.two ? 2 * stream_kh2(sp.ppl) : stream_k1(sp.ppl), sp.nsx, 0};
+            const int plan[6] = {64 * sp.ppl, 0, sp.mw_nwv ? sp.mw_nwv : sp.two ? 2 : 1,
+                                 sp.mw_nwv ? sp.mw_nwv * sp.mw_kh : sp.two ? 2 * stream_kh2(sp.ppl) : stream_k1(sp.ppl), sp.nsx, 0};
             memcpy(out + 6 * s, plan, sizeof(plan));
             continue;
         }
@@ -1994,7 +2050,26 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                 }
                 const bool four = sp.ppl == 2 && (p->tuning[VA_TUNE_STREAM_WAVES] == 4 || (p->tuning[VA_TUNE_STREAM_WAVES] == 0 && VA_STREAM4_DEFAULT));
 #endif
-                for (int it = queued ? p->iters : 0; it < p->iters;) {
+                // pipelines of three or four waves: the passes share the iterations as evenly as possible, so that every pass
+                // is deep enough to end in the last wave (K > (waves - 1) x levels per wave); otherwise the forms below run
+                int mw_n = 0, mw_base = 0, mw_extra = 0;
+                if (sp.mw_nwv && !queued) {
+                    const int kmax = sp.mw_nwv * sp.mw_kh, kmin = (sp.mw_nwv - 1) * sp.mw_kh + 1;
+                    mw_n = va_cdiv(p->iters, kmax);
+                    mw_base = p->iters / mw_n;
+                    mw_extra = p->iters % mw_n;
+                    if (mw_base < kmin) mw_n = 0;
+                }
+                for (int i = 0; i < mw_n; ++i) {
+                    sa.K = mw_base + (i < mw_extra ? 1 : 0);
+                    sa.sin = state[cur];
+                    sa.sout = state[cur ^ 1];
+                    sa.rev = VA_REV ? (launches & 1) : 0;
+                    launch_stream_mw(sp.mw_nwv, sp.mw_kh, p->fast_math != 0, grid, st, sa);
+                    cur ^= 1;
+                    ++launches;
+                }
+                for (int it = (queued || mw_n) ? p->iters : 0; it < p->iters;) {
                     const int rem = p->iters - it;
                     const int kh2 = stream_kh2(sp.ppl), k1 = stream_k1(sp.ppl);
                     const bool w2 = two && rem > kh2 && !sp.deep1;  // the two-wave kernel needs its last level in the second wave
