@@ -85,14 +85,17 @@ def test_tile_plan_of_the_benchmark_pyramid():
         ppl3 = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 8, stream_ppl=3))
         assert [(d["tile_w"], d["block_iters"], d["tiles_x"]) for d in ppl3] == [(192, 10, 2), (192, 10, 1), (192, 10, 1), (192, 10, 1), (192, 10, 1)]
     else:  # a default build refuses the experiment switches loudly instead of silently running something else
-        for kw in (dict(tile_mask=1 << 9), dict(stream_ppl=3), dict(stream_waves=3), dict(stream_waves=4), dict(stream_waves=5), dict(stream_waves=6), dict(stream_waves=9), dict(stream_waves=12), dict(stream_queue=1),
+        for kw in (dict(tile_mask=1 << 9), dict(stream_ppl=3), dict(stream_waves=3), dict(stream_waves=4), dict(stream_waves=5), dict(stream_waves=6), dict(stream_waves=10), dict(stream_waves=12), dict(stream_queue=1),
                    dict(rows_levels=1), dict(rows_cfg=40)):
             assert _ffi.lib().va_tvl1_workspace_bytes(224, 224, 1, 2, _ffi.default_tvl1_params(epsilon=0.0, **kw)) == 0, kw
             assert b"VA_EXPERIMENTS" in _ffi.lib().va_last_error()
     everywhere = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 8))
     assert [(d["tile_w"], d["tiles_x"]) for d in everywhere] == [(128, 2), (128, 2), (128, 2), (128, 1), (128, 1)]
-    hd = flow.tile_plan(1280, 720, _ffi.default_tvl1_params(epsilon=0.0))  # wide levels: one wave, 10 per pass, halo 10
+    hd = flow.tile_plan(1280, 720, _ffi.default_tvl1_params(epsilon=0.0))  # wide levels: four waves x 3 levels, 12 per pass, halo 12
     assert [(d["tile_w"], d["waves"], d["block_iters"], d["tiles_x"]) for d in hd] == [
+        (128, 4, 12, 13), (128, 4, 12, 10), (128, 4, 12, 8), (128, 4, 12, 7), (128, 4, 12, 5)]
+    hd1 = flow.tile_plan(1280, 720, _ffi.default_tvl1_params(epsilon=0.0, stream_waves=1))  # one wave, 10 per pass, halo 10
+    assert [(d["tile_w"], d["waves"], d["block_iters"], d["tiles_x"]) for d in hd1] == [
         (128, 1, 10, 12), (128, 1, 10, 10), (128, 1, 10, 8), (128, 1, 10, 6), (128, 1, 10, 5)]
     plan = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=0xFF))  # register tiles only
     assert [(d["tile_w"], d["tile_h"], d["waves"], d["block_iters"]) for d in plan] == [

@@ -40,6 +40,9 @@ def test_the_hot_kernels_keep_their_occupancy(kernels):
     for name in ("k_iter_stream<2, 4, 4, false, 1>", "k_iter_stream<2, 5, 4, false, 1>"):
         assert name in by, name
         assert by[name]["vgpr"] + by[name]["agpr"] <= 168 and by[name]["lds"] <= 81920 and by[name]["max_wg"] == 256, by[name]
+    # 4 x 3 levels (the wide levels): four waves per SIMD, three workgroups per CU
+    r43 = by["k_iter_stream<2, 3, 4, false, 1>"]
+    assert r43["vgpr"] + r43["agpr"] <= 128 and r43["lds"] <= 54613, r43
     img14 = [r for r in kernels if "k_conv3x3_img14" in r["mangled"]]  # (llvm-cxxfilt does not demangle the bf16 instantiations)
     assert len(img14) == 4 and all(r["vgpr"] + r["agpr"] <= 256 and r["lds"] <= 163840 and r["max_wg"] == 512 for r in img14), img14
     # four workgroups per CU for the tap-major bf16 kernel (<= 128 registers, <= 40 KB of LDS)

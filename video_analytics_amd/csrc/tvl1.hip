@@ -1396,7 +1396,7 @@ struct StreamPick {
     int mw_nwv, mw_kh;  // > 0: the pipeline of mw_nwv waves x mw_kh levels (3 or 4 waves; stream_waves >= 7)
 };
 // stream_waves >= 7: pipelines of three or four waves (waves x levels per wave)
-constexpr int kMwShapes[][2] = {{4, 4}, {4, 5}, {3, 5}, {3, 6}, {4, 6}, {4, 3}};
+constexpr int kMwShapes[][2] = {{4, 4}, {4, 5}, {4, 3}, {3, 5}, {3, 6}, {4, 6}};  // 7, 8, 9: compiled always; 10 ... 12: VA_EXPERIMENTS
 constexpr int kNumMwShapes = (int)(sizeof(kMwShapes) / sizeof(kMwShapes[0]));
 constexpr int kMwFirst = 7;
 // Pixels per lane of k_iter_stream: 2 (128-column strips) unless va_tvl1_params.stream_ppl asks for 3 (192-column
@@ -1432,11 +1432,11 @@ void launch_stream_mw1(bool fast, dim3 grid, hipStream_t st, const StreamArgs& s
 void launch_stream_mw(int nwv, int kh, bool fast, dim3 grid, hipStream_t st, const StreamArgs& sa)
 {
     if (nwv == 4 && kh == 5) return launch_stream_mw1<4, 5>(fast, grid, st, sa);
+    if (nwv == 4 && kh == 3) return launch_stream_mw1<4, 3>(fast, grid, st, sa);
 #ifdef VA_EXPERIMENTS
     if (nwv == 3 && kh == 5) return launch_stream_mw1<3, 5>(fast, grid, st, sa);
     if (nwv == 3 && kh == 6) return launch_stream_mw1<3, 6>(fast, grid, st, sa);
     if (nwv == 4 && kh == 6) return launch_stream_mw1<4, 6>(fast, grid, st, sa);
-    if (nwv == 4 && kh == 3) return launch_stream_mw1<4, 3>(fast, grid, st, sa);
 #endif
     (void)nwv;
     (void)kh;
@@ -1465,15 +1465,19 @@ void stream_strips(const va_tvl1_params* p, int w, StreamPick& sp)
     // (4 x 4, whole columns per job), 179^2 28.4 / 33.5 (4 x 5), 114^2 12.4 / 14.4 (4 x 4, two chunks): four shallow waves
     // need a quarter of the strip x chunk jobs to fill the GPU, so that the levels are cut into fewer chunks of rows (each
     // chunk costs its halo rows and the pipeline's fill), and leave room for a third wave per SIMD.
-    // stream_waves: 0 = this choice, 2 = the two-wave form, 1 = one wave everywhere, 7 = 4 x 4 everywhere it fits,
-    // (VA_EXPERIMENTS) 8 ... 12 = the other shapes of kMwShapes.
+    // Levels with more than two strips (the 1280x720 pyramid): 4 x 3 levels (12 per pass, halo 12, 119 registers: four waves
+    // per SIMD, three workgroups per CU) -- 138 against 118 pairs/s for the one-wave form with 10 per pass (16 pairs).
+    // stream_waves: 0 = this choice, 2 = two waves where they fit (rounds 1-2), 1 = one wave everywhere, 7 / 8 / 9 = 4 x 4 /
+    // 4 x 5 / 4 x 3 wherever a strip keeps valid columns, (VA_EXPERIMENTS) 10 ... 12 = 3 x 5, 3 x 6, 4 x 6.
     const int sw = p->tuning[VA_TUNE_STREAM_WAVES];
     int shape = -1;
     if (sw >= kMwFirst && sw < kMwFirst + kNumMwShapes) shape = sw - kMwFirst;
-    else if (sw == 0 && sp.two) shape = (w > SW && tiles_1d(w, SW, 20) <= 2) ? 1 : 0;
-    if (shape >= 0 && sp.two && sp.ppl == 2) {
+    else if (sw == 0) shape = !sp.two ? 2 : (w > SW && tiles_1d(w, SW, 20) <= 2) ? 1 : 0;
+    if (shape >= 0 && sp.ppl == 2) {
         const int nwv = kMwShapes[shape][0], kh = kMwShapes[shape][1], hx = va_cdiv(nwv * kh, 2) * 2;
-        if (tiles_1d(w, SW, hx) <= 2) {  // like the two-wave form: only where the deeper x halo costs no third strip
+        // the default choice: like the two-wave form only where the deeper x halo costs no third strip; an explicit
+        // stream_waves >= 7 takes the shape wherever a strip keeps valid columns
+        if (2 * hx < SW && (sw >= kMwFirst || !sp.two || tiles_1d(w, SW, hx) <= 2)) {
             sp.mw_nwv = nwv;
             sp.mw_kh = kh;
             if (hx > sp.HX) sp.HX = hx;  // (a pass that falls back to the two-wave form runs with this halo too)
@@ -1488,7 +1492,10 @@ StreamPick pick_stream(const va_tvl1_params* p, int w, int h, int npairs)
     // chunks of rows: the number of jobs (strip x chunk x pair) that keeps the GPU busiest was measured with one and
     // with two concurrent calls on different HIP streams: ~1024 one-wave jobs, ~640 two-wave jobs per call (256 CUs x
     // 8 waves); rows per chunk not below 32
-    const int slots = p->tuning[VA_TUNE_STREAM_SLOTS] > 0 ? p->tuning[VA_TUNE_STREAM_SLOTS] : sp.mw_nwv ? 320 : (sp.two ? 640 : 1024);
+    // (four-wave jobs: 320 per call on the levels of at most two strips -- 256 ... 400 measured equal, 480 and more 5 % slower
+    // in the whole benchmark --, 1024 on the wide levels: 512 ... 1280 within 2 %, 2048 8 % slower)
+    const int slots = p->tuning[VA_TUNE_STREAM_SLOTS] > 0 ? p->tuning[VA_TUNE_STREAM_SLOTS]
+                      : sp.mw_nwv ? (sp.nsx <= 2 ? 320 : 1024) : (sp.two ? 640 : 1024);
     int nch = p->tuning[VA_TUNE_STREAM_CHUNKS];
     if (nch <= 0) nch = (int)((double)slots / ((double)npairs * sp.nsx) + 0.5);
     if (nch > h / 32) nch = h / 32;
@@ -1686,7 +1693,7 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
     VA_CHECK_ARG(!(p->tuning[VA_TUNE_STREAM_WAVES] == 3 && p->fast_math), "va_tvl1: stream_waves = 3 (one deep wave) is compiled for the exact arithmetic only");
     if (!kVaExperiments) {
         const int sw = p->tuning[VA_TUNE_STREAM_WAVES];
-        VA_CHECK_ARG(sw != 3 && sw != 4 && sw != 5 && sw != 6 && sw <= kMwFirst + 1 && p->tuning[VA_TUNE_STREAM_PPL] != 3 && p->tuning[VA_TUNE_STREAM_QUEUE] != 1 &&
+        VA_CHECK_ARG(sw != 3 && sw != 4 && sw != 5 && sw != 6 && sw <= kMwFirst + 2 && p->tuning[VA_TUNE_STREAM_PPL] != 3 && p->tuning[VA_TUNE_STREAM_QUEUE] != 1 &&
                          p->tuning[VA_TUNE_ROWS_LEVELS] <= 0 && p->tuning[VA_TUNE_ROWS_CFG] == 0 && !(p->tile_mask & kRowsBit),
                      "va_tvl1: this tuning value selects an experiment kernel (k_iter_rows, k_iter_stream_q, k_iter_stream4, one deep "
                      "wave, two chains per wave, four waves x four levels, 3 pixels per lane); build the library with -DVA_EXPERIMENTS (make EXPERIMENTS=1) to get them");

@@ -71,9 +71,9 @@ struct va_device_guard {
 enum {
     VA_TUNE_STREAM_LEVELS = 0,  // -1: the library decides per level; else bit s = pyramid level s iterates with the row pipeline
     VA_TUNE_STREAM_WAVES = 1,   // 0: default shape per level (four waves x 4 or 5 levels where they fit); 1: one-wave pipeline everywhere;
-                                // 2: the two-wave form (2 x 8 levels); 7 / 8: four waves x 4 / 5 levels wherever they fit;
+                                // 2: the two-wave form (2 x 8 levels); 7 / 8 / 9: four waves x 4 / 5 / 3 levels wherever they fit;
                                 // (VA_EXPERIMENTS) 3: one deep wave, 4: four jobs per workgroup, 5 / 6: two interleaved chains of levels
-                                // per wave (one deep wave / two waves), 9 ... 12: 3 x 5, 3 x 6, 4 x 6, 4 x 3 levels
+                                // per wave (one deep wave / two waves), 10 ... 12: 3 x 5, 3 x 6, 4 x 6 levels
     VA_TUNE_STREAM_CHUNKS = 2,  // 0: rows cut into as many chunks as fill the GPU; n > 0: n chunks (capped at h / 32)
     VA_TUNE_STREAM_SLOTS = 3,   // 0: default target number of strip x chunk x pair jobs per call
     VA_TUNE_ROWS_LEVELS = 4,    // (VA_EXPERIMENTS) -1 / bit set: levels iterated by the persistent row pipeline k_iter_rows
