@@ -884,8 +884,13 @@ struct StreamShape {
     static constexpr int lpos(int t) { return t + t / KC; }  // position of the wave's level t behind the wave's first level
 };
 // rows of per-warp constants the LDS ring holds: the oldest row a level reads at step s is s - (its pipeline position)
+// (three and four waves: the LAST level of the last wave takes the constants its neighbour level read one step earlier --
+// the same row -- out of registers, so that the ring's oldest row is never read: one row less, which is what lets three
+// 4 x 4 workgroups share a CU's 160 KB)
 template <int KH, int NWV, int NCH>
-constexpr int stream_ring_rows() { return NWV == 1 ? KH + NCH - 2 : NWV * (KH + NCH) - 2; }
+constexpr bool stream_keep_last() { return NWV >= 3 && NCH == 1 && KH >= 2; }
+template <int KH, int NWV, int NCH>
+constexpr int stream_ring_rows() { return NWV == 1 ? KH + NCH - 2 : NWV * (KH + NCH) - 2 - (stream_keep_last<KH, NWV, NCH>() ? 1 : 0); }
 
 template <int PPL>
 struct StreamRow {  // the six state fields of one row of a strip
@@ -1004,6 +1009,8 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
 #pragma clang loop unroll(full)
         for (int c = 0; c < (NCH > 1 ? NCH - 1 : 1); ++c) latch[c] = SR{zero, zero, zero, zero, zero, zero};
         R nst[kNF_STATE], nro[kNF_RO], rprev[kNF_RO] = {zero, zero, zero, zero};
+        constexpr bool KEEP = LAST && stream_keep_last<KH, NWV, NCH>();
+        R keep[kNF_RO] = {zero, zero, zero, zero};  // KEEP: the constants level KH - 2 worked with in the previous step = level KH - 1's of this one
 #pragma clang loop unroll(full)
         for (int f = 0; f < kNF_STATE; ++f) nst[f] = FIRST ? ld(rs_in, f, ys) : zero;
 #pragma clang loop unroll(full)
@@ -1137,11 +1144,20 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
                     if (i + 1 < KC) {
 #pragma clang loop unroll(full)
                         for (int c = 0; c < NCH; ++c) {
-                            const int slot = slot_of(c * KC + i + 1);
+                            if (KEEP && i + 1 == KH - 1) {  // (NCH == 1) the last level: the row level KH - 2 had one step ago
 #pragma clang loop unroll(full)
-                            for (int f = 0; f < kNF_RO; ++f) nq[c][f] = (VA_TIMING_SKIP & 8) ? q[c][f] : ring_get(slot, f);
+                                for (int f = 0; f < kNF_RO; ++f) nq[c][f] = keep[f];
+                            } else {
+                                const int slot = slot_of(c * KC + i + 1);
+#pragma clang loop unroll(full)
+                                for (int f = 0; f < kNF_RO; ++f) nq[c][f] = (VA_TIMING_SKIP & 8) ? q[c][f] : ring_get(slot, f);
+                            }
                         }
                         if (!(VA_TIMING_SKIP & 16)) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (KEEP && i == KH - 2) {
+#pragma clang loop unroll(full)
+                        for (int f = 0; f < kNF_RO; ++f) keep[f] = q[0][f];
                     }
 #pragma clang loop unroll(full)
                     for (int c = 0; c < NCH; ++c) level(c * KC + i, cc[c], q[c][0], q[c][1], q[c][2], q[c][3], 1.0f, std::true_type{});
@@ -1162,11 +1178,18 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
                         const float my = rin - 1 < h - 1 ? 1.0f : 0.0f;
                         if (FIRST && t == 0) {
                             level(0, cc[0], r0[0], r0[1], r0[2], r0[3], my, std::false_type{});
+                        } else if (KEEP && t == KH - 1) {
+                            level(t, cc[t / KC], keep[0], keep[1], keep[2], keep[3], my, std::false_type{});
                         } else {
                             const int slot = slot_of(t);
                             level(t, cc[t / KC], ring_get(slot, 0), ring_get(slot, 1), ring_get(slot, 2), ring_get(slot, 3), my, std::false_type{});
                         }
                     }
+                }
+                if constexpr (KEEP) {  // whether or not level KH - 2 worked in this step: the row it stands at is level KH - 1's next one
+                    const int slot = slot_of(KH - 2);
+#pragma clang loop unroll(full)
+                    for (int f = 0; f < kNF_RO; ++f) keep[f] = ring_get(slot, f);
                 }
             }
 #pragma clang loop unroll(full)
