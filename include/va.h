@@ -171,7 +171,8 @@ typedef struct va_tvl1_params {
                          128-column strip row by row through 10 iterations per pass) instead of the
                          register tiles; fixed-iteration mode only.  Bit 9 (512): iterate every level that fits one
                          strip (<= 256 columns) with the persistent row pipeline k_iter_rows, the others with the
-                         streaming kernel.  0 (default) = library choice per level.  Results do not depend on it. */
+                         streaming kernel.  Bit 10 (1024): the streaming kernel never lets the narrow last strips of two
+                         pairs share a wave (A/B switch).  0 (default) = library choice per level.  Results do not depend on it. */
     int tuning[8];    /* the library's own tuning / experiment switches (which kernel iterates which pyramid level, chunking of
                          rows, pipeline shapes: named in csrc/va_internal.h, VA_TUNE_*); va_tvl1_default_params fills in the
                          defaults (-1, 0, 0, 0, -1, 0, 0, 0) and callers leave them alone.  Results do not depend on any

@@ -70,10 +70,15 @@ def test_tile_plan_of_the_benchmark_pyramid():
     224x224 benchmark pyramid in fixed-iteration mode, and the epsilon mode's forced block depth 1."""
     from video_analytics_amd import _ffi, flow
     plan = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0))
-    # the 224^2, 179^2 (two 128-column strips each) and 114^2 (one strip) levels stream through FOUR waves (round 3): 4 x 4
-    # levels = 16 iterations per pass, 4 x 5 = 20 on 179^2, where a 20-column halo still costs no third strip;
-    # 143^2 (strips 56 % full) and 91^2 (too few jobs) iterate on 64x64 register tiles -- the measured choice
+    # the 224^2, 179^2, 143^2 (two 128-column strips each) and 114^2 (one strip) levels stream through FOUR waves (round 3): 4 x 4
+    # levels = 16 iterations per pass, 4 x 5 = 20 on 179^2 and 143^2, where a 20-column halo still costs no third strip;
+    # 91^2 (too few jobs) iterates on 64x64 register tiles -- the measured choice
     assert [(d["tile_w"], d["tile_h"], d["waves"], d["block_iters"], d["tiles_x"]) for d in plan] == [
+        (128, 0, 4, 16, 2), (128, 0, 4, 20, 2), (128, 0, 4, 20, 2), (128, 0, 4, 16, 1), (64, 64, 4, 16, 2)]
+    # (143^2 streams too since the last strips of two pairs share a wave: 1.5 strips per pair, 74 % full; without the sharing
+    # -- tile_mask bit 10 -- it stays on the register tiles)
+    plain = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, tile_mask=1 << 10))
+    assert [(d["tile_w"], d["tile_h"], d["waves"], d["block_iters"], d["tiles_x"]) for d in plain] == [
         (128, 0, 4, 16, 2), (128, 0, 4, 20, 2), (64, 64, 4, 12, 3), (128, 0, 4, 16, 1), (64, 64, 4, 16, 2)]
     two = flow.tile_plan(224, 224, _ffi.default_tvl1_params(epsilon=0.0, stream_waves=2))  # the two-wave form of rounds 1-2
     assert [(d["tile_w"], d["tile_h"], d["waves"], d["block_iters"], d["tiles_x"]) for d in two] == [

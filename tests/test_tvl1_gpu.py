@@ -101,11 +101,18 @@ def test_streaming_kernel_three_and_four_wave_forms_bit_exact(oracle_tvl1, waves
     # a warp step share the iterations evenly (44 = 15 + 15 + 14, 57 = 19 + 19 + 19, 29 = 15 + 14): every pass must end in the
     # last wave, otherwise the step falls back to the two-wave form (10, 23); 300 columns: three strips, where only the
     # one-wave form runs; chunks of rows; the smallest frames
-    gray = _frames(2, 2, H, W, seed=3 * H + W)
+    # Shared last strips: where the last strip of a row fits 32 lanes (143, 131, 130 columns; the third strip of 300), ONE
+    # wave carries the last strips of two consecutive pairs in its two halves -- three pairs here: a couple and a single
+    # one whose partner lanes idle; tile_mask bit 10 switches the sharing off (same results either way)
+    gray = _frames(3, 2, H, W, seed=3 * H + W)
     for iters, warps, nscales in ((16, 1, 1), (44, 2, 3), (29, 1, 2), (57, 1, 1), (40, 1, 2), (23, 1, 1)):
         ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=iters, warps=warps, nscales=nscales, tile_mask=1 << 8,
                              stream_chunks=nch, stream_waves=waves)
         assert np.array_equal(out, ref), "max abs diff %g (iters %d)" % (np.abs(out - ref).max(), iters)
+    if waves in (0, 8):
+        ref, out = _run_both(oracle_tvl1, gray, epsilon=0.0, iters=40, warps=1, nscales=2, tile_mask=(1 << 8) | (1 << 10),
+                             stream_chunks=nch, stream_waves=waves)
+        assert np.array_equal(out, ref), "max abs diff %g (no shared strips)" % np.abs(out - ref).max()
 
 
 @pytest.mark.parametrize("ppl", [2, 3])
@@ -406,7 +413,7 @@ def test_bad_arguments_raise_value_error():
     with pytest.raises(ValueError):
         vflow.tvl1_flow(fr, out=torch.empty(1, 2, 64, 64, device="cuda"))  # out for 2 pairs must be [2,2,64,64]
     with pytest.raises(ValueError):
-        vflow.tvl1_flow(fr, tile_mask=1 << 10)  # 8 tile candidates + the streaming bit + the row-pipeline bit
+        vflow.tvl1_flow(fr, tile_mask=1 << 11)  # 8 tile candidates + the streaming bit + the row-pipeline bit + the no-shared-strips bit
     with pytest.raises(ValueError):
         vflow.tvl1_flow(fr, rows_cfg=1000)
     with pytest.raises(ValueError):

@@ -854,6 +854,11 @@ struct StreamArgs {
     int K;                // iterations in this launch (<= KS)
     int pair0, rev;
     float l_t, taut, theta;
+    // narrow = 1: the last strip of a row needs at most 64 columns (32 lanes), so that ONE wave carries the last strips of TWO
+    // consecutive pairs, pair 2c in its lanes 0..31 and pair 2c + 1 in its lanes 32..63 (the 143^2 level: 128 + 64 lane-columns
+    // per row instead of 2 x 128).  What crosses the lane 31 | 32 boundary is the left halo of the one and columns beyond the
+    // image of the other.  The grid then is ((2 nsx - 1) x nch, couples of pairs); npairs: pairs of this launch.
+    int narrow, npairs;
 };
 
 // KH levels per wave, NWV waves per workgroup.  NWV = 1: the wave is the whole pipeline (K <= KH iterations per pass).
@@ -900,8 +905,9 @@ struct StreamRow {  // the six state fields of one row of a strip
 template <int PPL, int KH, int NWV, bool FAST, int SUBS = 1, int NCH = 1>
 __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, const int job, const int K,
                                            const float* __restrict__ sin_all, float* __restrict__ sout_all, const int sub = 0,
-                                           const int role = -1, const bool active = true, const int steps_pad = 0)
-{
+                                           const int role = -1, const bool active = true, const int steps_pad = 0, const int half = 0)
+{   // half: 0 = a whole-wave strip of `pair`; 1 = the shared last strip of `pair` (lanes 0..31) and `pair + 1` (lanes 32..63);
+    // 2 = the same without a second pair (lanes 32..63 idle)
     typedef Row<PPL> R;
     typedef StreamRow<PPL> SR;
     typedef StreamShape<KH, NCH> SH;
@@ -925,8 +931,8 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
     const int wv = NWV == 1 ? 0 : role >= 0 ? role : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ox = sx * (SW - 2 * a.HX);
     const int vx0 = ox + (sx > 0 ? a.HX : 0), vx1 = (sx == a.nsx - 1) ? pitch : ox + SW - a.HX;
-    const int x0 = ox + PPL * lane;  // (the pitch, the halo and so every strip origin are multiples of PPL)
-    const bool colok = x0 < pitch;
+    const int x0 = ox + PPL * (half ? (lane & 31) : lane);  // (the pitch, the halo and so every strip origin are multiples of PPL)
+    const bool colok = x0 < pitch && !(half == 2 && lane >= 32);
     const bool stok = colok && x0 >= vx0 && x0 < vx1;
     const int a0 = ch * a.R, b0 = d_min(h, a0 + a.R);
     const int ys = d_max(0, a0 - K), ye = d_min(h, b0 + K);
@@ -935,13 +941,16 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
     // pitch read column 0 (finite values that no valid pixel can see: their differences are multiplied by mx = 0) and
     // never store.
     const int planeb = (int)(a.plane * sizeof(float)), pitchb = pitch * (int)sizeof(float);
+    const int npr = half == 1 ? 2 : 1;  // pairs the resources span (the planes of consecutive pairs follow each other)
     const __amdgpu_buffer_rsrc_t rs_ro = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.ro + (size_t)pair * kNF_RO * a.plane), 0, kNF_RO * planeb, 0x00020000);
+        const_cast<float*>(a.ro + (size_t)pair * kNF_RO * a.plane), 0, npr * kNF_RO * planeb, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(sin_all + (size_t)pair * kNF_STATE * a.plane), 0, kNF_STATE * planeb, 0x00020000);
+        const_cast<float*>(sin_all + (size_t)pair * kNF_STATE * a.plane), 0, npr * kNF_STATE * planeb, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(sout_all + (size_t)pair * kNF_STATE * a.plane, 0,
-                                                                           kNF_STATE * planeb, 0x00020000);
-    const int loff = colok ? x0 * (int)sizeof(float) : 0;
+                                                                           npr * kNF_STATE * planeb, 0x00020000);
+    const bool second = half == 1 && lane >= 32;  // this lane works on pair + 1
+    const int loff = colok ? x0 * (int)sizeof(float) + (second ? kNF_STATE * planeb : 0) : 0;     // state planes
+    const int loff_ro = colok ? x0 * (int)sizeof(float) + (second ? kNF_RO * planeb : 0) : 0;     // per-warp constants
 
     R mx;
     mx.t = 0.0f;
@@ -991,6 +1000,7 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
     }
 
     auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int f, int y) -> R { return row_load<PPL>(r, loff, f * planeb + y * pitchb); };
+    auto ld_ro = [&](int f, int y) -> R { return row_load<PPL>(rs_ro, loff_ro, f * planeb + y * pitchb); };
     auto st = [&](const R& v, int f, int y) { row_store<PPL>(v, rs_out, loff, f * planeb + y * pitchb); };
 
     // the last valid row b0 - 1 leaves the last ACTIVE level (K - 1) when row b0 (or the dummy row h) comes in, and then
@@ -1014,7 +1024,7 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
 #pragma clang loop unroll(full)
         for (int f = 0; f < kNF_STATE; ++f) nst[f] = FIRST ? ld(rs_in, f, ys) : zero;
 #pragma clang loop unroll(full)
-        for (int f = 0; f < kNF_RO; ++f) nro[f] = FIRST ? ld(rs_ro, f, ys) : zero;
+        for (int f = 0; f < kNF_RO; ++f) nro[f] = FIRST ? ld_ro(f, ys) : zero;
 
         // One level: phase A on the incoming row C (k_iter_tile's arithmetic, operation for operation), phase B on the
         // row above it (whose lower neighbour is the row just computed); the level keeps the incoming p and the new u,
@@ -1086,7 +1096,7 @@ __device__ __forceinline__ void stream_job(const StreamArgs& a, const int pair, 
 #pragma clang loop unroll(full)
                     for (int f = 0; f < kNF_STATE; ++f) nst[f] = ld(rs_in, f, rn);
 #pragma clang loop unroll(full)
-                    for (int f = 0; f < kNF_RO; ++f) nro[f] = ld(rs_ro, f, rn);
+                    for (int f = 0; f < kNF_RO; ++f) nro[f] = ld_ro(f, rn);
                 }
                 if constexpr (NWV > 1) {  // the constants of row s - 1 go into the ring now that the barrier has passed
                     const int sl = s0 == 0 ? NRING - 1 : s0 - 1;
@@ -1287,7 +1297,21 @@ __global__ void __launch_bounds__(NWV * 64)
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
         if (a.rev) lid = nb - 1 - lid;
     }
-    stream_job<PPL, KH, NWV, FAST, 1, NCH>(a, a.pair0 + (int)(lid / gridDim.x), (int)(lid % gridDim.x), a.K, a.sin, a.sout);
+    if (!a.narrow) {
+        stream_job<PPL, KH, NWV, FAST, 1, NCH>(a, a.pair0 + (int)(lid / gridDim.x), (int)(lid % gridDim.x), a.K, a.sin, a.sout);
+        return;
+    }
+    // shared last strips: per couple of pairs and chunk 2 (nsx - 1) whole-wave strips and ONE wave for both last strips
+    const int couple = (int)(lid / gridDim.x), jx = (int)(lid % gridDim.x), per = 2 * a.nsx - 1;
+    const int ch = jx / per, r = jx % per, first = 2 * couple;
+    int which = 0, sx = a.nsx - 1, half = first + 1 < a.npairs ? 1 : 2;
+    if (r < 2 * (a.nsx - 1)) {
+        which = r / (a.nsx - 1);
+        sx = r % (a.nsx - 1);
+        half = 0;
+        if (first + which >= a.npairs) return;  // an odd number of pairs: the last couple has no second one
+    }
+    stream_job<PPL, KH, NWV, FAST, 1, NCH>(a, a.pair0 + first + which, ch * a.nsx + sx, a.K, a.sin, a.sout, 0, -1, true, 0, half);
 }
 
 #ifdef VA_EXPERIMENTS  // measured-slower kernel families: k_iter_stream4, k_iter_stream_q, k_iter_rows
@@ -1413,10 +1437,12 @@ static_assert(kStreamKH2 == 8, "k_iter_stream4 instantiates stream_job<2, 8, 2>"
 constexpr int stream_k1(int ppl) { return ppl == 2 ? kStreamK1 : 5; }
 constexpr int stream_kh2(int ppl) { return ppl == 2 ? kStreamKH2 : 5; }
 constexpr int kStreamBit = 1 << 8;  // va_tvl1_params.tile_mask bit: iterate with k_iter_stream
+constexpr int kNoNarrowBit = 1 << 10;  // va_tvl1_params.tile_mask bit: no shared last strips (StreamArgs.narrow) -- A/B and tests
 struct StreamPick {
     int nsx, nch, R, HX, two, ppl, deep1;
     int chains;  // chains of levels per wave (stream_job, NCH): 1, or 2 with stream_waves = 5 (one deep wave) / 6 (two waves)
     int mw_nwv, mw_kh;  // > 0: the pipeline of mw_nwv waves x mw_kh levels (3 or 4 waves; stream_waves >= 7)
+    int narrow;         // the last strip of a row fits 32 lanes: two pairs' last strips share a wave (StreamArgs.narrow)
 };
 // stream_waves >= 7: pipelines of three or four waves (waves x levels per wave)
 constexpr int kMwShapes[][2] = {{4, 4}, {4, 5}, {4, 3}, {3, 5}, {3, 6}, {4, 6}};  // 7, 8, 9: compiled always; 10 ... 12: VA_EXPERIMENTS
@@ -1505,6 +1531,10 @@ void stream_strips(const va_tvl1_params* p, int w, StreamPick& sp)
             sp.mw_kh = kh;
             if (hx > sp.HX) sp.HX = hx;  // (a pass that falls back to the two-wave form runs with this halo too)
             sp.nsx = tiles_1d(w, SW, sp.HX);
+            // the last strip starts at (nsx - 1) (SW - 2 HX); if the level (with its pitch padding) ends within 64 columns of
+            // that, the strip is narrow (tile_mask bit 10: never)
+            const int pitch4 = (w + 3) & ~3;
+            sp.narrow = sp.nsx >= 2 && !(p->tile_mask & kNoNarrowBit) && (sp.nsx - 1) * (SW - 2 * sp.HX) + 64 >= pitch4;
         }
     }
 }
@@ -1534,15 +1564,16 @@ bool level_streams(const va_tvl1_params* p, bool eps, int s, int w, int h, size_
 {
     if (eps || (double)plane * kNF_STATE * sizeof(float) >= 2147483648.0) return false;  // 32-bit buffer offsets
     if (p->tile_mask & kStreamBit) return true;
-    if (p->tile_mask != 0) return false;
+    if ((p->tile_mask & ~kNoNarrowBit) != 0) return false;
     if (p->tuning[VA_TUNE_STREAM_LEVELS] >= 0) return ((p->tuning[VA_TUNE_STREAM_LEVELS] >> s) & 1) != 0;
     StreamPick sp{};
     stream_strips(p, w, sp);
     // measured per level of the 224x224 pyramid (320 pairs, two streams; profiles/README.md): the row pipeline wins on 224^2
     // (two strips 88 % full), 179^2 (70 %) and 114^2 (one strip, 89 %), the register tiles on 143^2 (56 %) and 91^2 (71 %
     // of one strip, too few jobs); every level of the 1280x720 pyramid (80..85 %) streams
-    const double fill = (double)w / (64.0 * sp.ppl * sp.nsx), px = (double)w * h;
-    return (fill >= 0.85 && px >= 10000.0) || (fill >= 0.69 && px >= 30000.0);
+    // (round 3: with the last strips of two pairs sharing a wave 143^2 fills 74 % of 1.5 strips: 18.9 ms against 21.6 on tiles)
+    const double fill = (double)w / (64.0 * sp.ppl * (sp.nsx - (sp.narrow ? 0.5 : 0.0))), px = (double)w * h;
+    return (fill >= 0.85 && px >= 10000.0) || (fill >= 0.69 && px >= 20000.0);
 }
 
 // ---- k_iter_rows: which levels, which pipeline shape
@@ -1600,7 +1631,7 @@ int level_kernel(const va_tvl1_params* p, bool eps, int s, int w, int h, int pit
     if (eps || (double)plane * kNF_STATE * sizeof(float) >= 2147483648.0) return LK_TILE;
     const bool rows_ok = pick_rows(p, h, pitch, *rp);
     if (p->tile_mask & kRowsBit) return rows_ok ? LK_ROWS : LK_STREAM;
-    if (p->tile_mask != 0) return level_streams(p, eps, s, w, h, plane) ? LK_STREAM : LK_TILE;
+    if ((p->tile_mask & ~kNoNarrowBit) != 0) return level_streams(p, eps, s, w, h, plane) ? LK_STREAM : LK_TILE;
     if (p->tuning[VA_TUNE_ROWS_LEVELS] >= 0 || p->tuning[VA_TUNE_STREAM_LEVELS] >= 0) {
         if (p->tuning[VA_TUNE_ROWS_LEVELS] >= 0 && ((p->tuning[VA_TUNE_ROWS_LEVELS] >> s) & 1) && rows_ok) return LK_ROWS;
         return p->tuning[VA_TUNE_STREAM_LEVELS] >= 0 && ((p->tuning[VA_TUNE_STREAM_LEVELS] >> s) & 1) ? LK_STREAM : LK_TILE;
@@ -1704,7 +1735,7 @@ int check_params(const va_tvl1_params* p, int w, int h, int n_seq, int fps)
     VA_CHECK_ARG(p->tau > 0.0f && p->lambda > 0.0f && p->theta > 0.0f, "va_tvl1: tau, lambda, theta must be > 0");
     VA_CHECK_ARG(p->block_iters >= 0 && p->block_iters <= 64, "va_tvl1: block_iters must be in [0,64]");
     VA_CHECK_ARG(p->fast_math == 0 || p->fast_math == 1, "va_tvl1: fast_math must be 0 or 1");
-    VA_CHECK_ARG(p->tile_mask >= 0 && p->tile_mask < (1 << (kNumCfgs + 2)), "va_tvl1: tile_mask must be in [0, %d]", (1 << (kNumCfgs + 2)) - 1);
+    VA_CHECK_ARG(p->tile_mask >= 0 && p->tile_mask < (1 << (kNumCfgs + 3)), "va_tvl1: tile_mask must be in [0, %d]", (1 << (kNumCfgs + 3)) - 1);
     VA_CHECK_ARG(p->tuning[VA_TUNE_ROWS_LEVELS] >= -1 && p->tuning[VA_TUNE_ROWS_LEVELS] < (1 << kMaxScales) && p->tuning[VA_TUNE_ROWS_CFG] >= 0 && p->tuning[VA_TUNE_ROWS_CFG] < 256,
                  "va_tvl1: rows_levels must be -1 or a level bit set, rows_cfg in [0,255]");
     VA_CHECK_ARG(p->tuning[VA_TUNE_STREAM_PPL] == 0 || p->tuning[VA_TUNE_STREAM_PPL] == 2 || p->tuning[VA_TUNE_STREAM_PPL] == 3, "va_tvl1: stream_ppl must be 0 (default), 2 or 3");
@@ -2046,6 +2077,10 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                 sa.taut = a.taut;
                 sa.theta = a.theta;
                 const dim3 grid(sp.nsx * sp.nch, nc);
+                // the four-wave passes of a level whose last strip fits 32 lanes: one wave for the last strips of two pairs
+                const bool narrow = sp.narrow != 0;
+                const dim3 grid_mw = narrow ? dim3((2 * sp.nsx - 1) * sp.nch, va_cdiv(nc, 2)) : grid;
+                sa.npairs = nc;
                 const bool two = sp.two != 0;
                 bool queued = false;
 #ifdef VA_EXPERIMENTS
@@ -2095,7 +2130,9 @@ extern "C" int va_tvl1_flow(va_ctx* ctx, const void* frames, int frames_are_u8, 
                     sa.sin = state[cur];
                     sa.sout = state[cur ^ 1];
                     sa.rev = VA_REV ? (launches & 1) : 0;
-                    launch_stream_mw(sp.mw_nwv, sp.mw_kh, p->fast_math != 0, grid, st, sa);
+                    sa.narrow = narrow ? 1 : 0;
+                    launch_stream_mw(sp.mw_nwv, sp.mw_kh, p->fast_math != 0, grid_mw, st, sa);
+                    sa.narrow = 0;
                     cur ^= 1;
                     ++launches;
                 }
