@@ -115,6 +115,24 @@ def test_streaming_kernel_three_and_four_wave_forms_bit_exact(oracle_tvl1, waves
         assert np.array_equal(out, ref), "max abs diff %g (no shared strips)" % np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("H,W,nseq", [(143, 143, 7), (720, 1280, 3), (150, 300, 5), (224, 224, 4)])
+def test_shared_last_strips_equal_unshared_on_many_pairs(H, W, nseq):
+    # the narrow last strips of two consecutive pairs in one wave (lanes 0..31 / 32..63) against one wave per strip (tile_mask
+    # bit 10) and against the two-wave form, GPU against GPU: odd and even numbers of pairs, thirteen strips (1280 columns),
+    # a level without a narrow strip (224); the oracle comparison of the same kernels is the parametrised test above
+    from video_analytics_amd import flow as vflow
+    gray = _frames(nseq, 3, H, W, seed=H + W + nseq).cuda()  # 2 pairs per sequence
+    if nseq % 2 == 0:
+        gray = gray[:, :2]  # one pair per sequence
+    gray = torch.cat([gray, gray[:1]], 0) if H == 143 else gray
+    kw = dict(epsilon=0.0, iters=45, warps=2, nscales=2, stream_chunks=0)
+    shared = vflow.tvl1_flow(gray, tile_mask=1 << 8, **kw)
+    plain = vflow.tvl1_flow(gray, tile_mask=(1 << 8) | (1 << 10), **kw)
+    two = vflow.tvl1_flow(gray, tile_mask=1 << 8, stream_waves=2, **kw)
+    assert torch.equal(shared, plain) and torch.equal(shared, two)
+    assert bool(torch.isfinite(shared).all())
+
+
 @pytest.mark.parametrize("ppl", [2, 3])
 @pytest.mark.parametrize("H,W,nch", [(179, 179, 0), (143, 143, 2), (100, 64, 3), (64, 300, 1), (150, 400, 3), (57, 131, 1), (33, 190, 1),
                                      (129, 225, 2), (40, 700, 1), (16, 16, 0)])
