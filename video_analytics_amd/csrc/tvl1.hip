@@ -22,10 +22,11 @@
 //                  (temporal blocking with a K-pixel overlapped halo).  Horizontal neighbours come
 //                  from the adjacent lane by DPP wave shifts, vertical neighbours of the patch's
 //                  first/last row from the adjacent wave through a 2-row LDS exchange.
-//   k_iter_stream  One wave (or a pipeline of two) owns a strip of 128 columns and streams its rows
-//                  top to bottom ONCE per launch, carrying every row through K iterations on the way
-//                  (time-skewed: level t works one row behind level t-1); no y halo, no barrier in
-//                  the one-wave form.  Used where the strips are well filled (level_streams()).
+//   k_iter_stream  A pipeline of FOUR waves (one or two in the fallback forms) owns a strip of 128
+//                  columns and streams its rows top to bottom ONCE per launch, carrying every row
+//                  through K iterations on the way (time-skewed: level t works one row behind level
+//                  t-1; a wave hands its rows on to the next through LDS); no y halo.  Used where
+//                  the strips are well filled (level_streams()).
 // Either way the HBM traffic per pixel-iteration falls from the algorithmic 64 B to about
 // 64 B / K / efficiency.
 #include "va_internal.h"
@@ -1491,9 +1492,10 @@ void launch_stream_mw(int nwv, int kh, bool fast, dim3 grid, hipStream_t st, con
     (void)kh;
     launch_stream_mw1<4, 4>(fast, grid, st, sa);
 }
-// Strips of a level.  Two-wave pipeline (16 iterations per pass) where the deeper x halo costs nothing, i.e. where the
-// level has no interior strip (w <= 224); wider levels use the one-wave pipeline (10 per pass, halo 10: measured on
-// the 1280x720 pyramid).  va_tvl1_params.stream_waves = 1 (experiment switch): one-wave everywhere.
+// Strips of a level and the shape of the pipeline that carries them (see the comment on the four-wave forms below).  The
+// forms of rounds 1-2 remain as explicit choices and as fallbacks for passes too short for four waves: two waves x 8
+// levels (16 iterations per pass) where the 16-column x halo costs no third strip (w <= 224), one wave x 10 levels
+// (halo 10) on wider levels.  va_tvl1_params.stream_waves = 1: one wave everywhere; 2: these two.
 void stream_strips(const va_tvl1_params* p, int w, StreamPick& sp)
 {
     sp.ppl = stream_ppl(p, w);
